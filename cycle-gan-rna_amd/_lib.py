@@ -1,0 +1,93 @@
+"""ctypes binding of libcgrna.so (the C ABI declared in include/cgrna.h).
+
+torch must be imported before the library is loaded so that both share one HIP
+runtime (the library's libamdhip64.so.7 dependency then resolves to the copy
+torch already mapped).  There is no fallback: a missing library is an error.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (loads the HIP runtime first, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcgrna.so")
+
+P = C.c_void_p
+I = C.c_int
+F = C.c_float
+Z = C.c_size_t
+
+
+class GlossDesc(C.Structure):
+    _fields_ = [("n_terms", C.c_int * 5), ("slot", (C.c_int * 4) * 5), ("weight", (C.c_double * 4) * 5),
+                ("lambda_", C.c_double * 5), ("ema_alpha", C.c_double)]
+
+
+SIGNATURES = {
+    "cg_version": ([], I),
+    "cg_gemm": ([P, I, P, I, P, I, I, I, I, I, I, I, P, I, P, I, P, I, F, I, P], I),
+    "cg_bn_fwd": ([P, I, P, I, I, I, P, P, F, P, P, P, P, F, F, P, I, P, I, P, I, P], I),
+    "cg_bn_eval": ([P, I, P, I, I, I, P, P, P, P, F, F, P], I),
+    "cg_bn_bwd": ([P, I, P, I, P, I, P, I, P, I, P, P, P, P, P, I, P, P, F, I, I, P], I),
+    "cg_bn_bwd_bwd": ([P, I, P, I, P, I, P, I, P, I, P, I, P, P, P, P, P, I, I, P], I),
+    "cg_axpby": ([P, I, F, P, I, F, P, I, I, I, P], I),
+    "cg_mul": ([P, I, P, I, P, I, I, I, P], I),
+    "cg_fill_coef": ([P, I, I, I, P, I, F, P], I),
+    "cg_to_bf16": ([P, I, P, I, I, I, P], I),
+    "cg_embed_gather": ([P, I, P, I, P, I, I, I, P], I),
+    "cg_embed_scatter": ([P, I, P, I, P, I, I, I, I, P], I),
+    "cg_reparam_fwd": ([P, I, P, I, P, I, I, P], I),
+    "cg_reparam_bwd": ([P, I, P, I, P, I, P, P, I, F, I, I, P], I),
+    "cg_libsize_fwd": ([P, I, P, I, P, F, I, I, P], I),
+    "cg_libsize_bwd": ([P, I, P, I, P, I, P, F, I, I, P], I),
+    "cg_gp_interp": ([P, I, P, I, P, I, P, I, I, P], I),
+    "cg_gp_penalty": ([P, I, P, P, I, F, I, I, P], I),
+    "cg_reduce_sum": ([P, P, P, I, I, I, P], I),
+    "cg_reduce_l1": ([P, P, P, I, P, I, I, I, P], I),
+    "cg_reduce_centroid_sq": ([P, P, P, I, P, I, P, I, I, I, P], I),
+    "cg_reduce_kl": ([P, P, P, I, I, I, P], I),
+    "cg_colsum": ([P, P, I, I, I, F, I, P], I),
+    "cg_reduce_sqdiff": ([P, P, P, I, P, I, I, I, P], I),
+    "cg_colvar_mean": ([P, P, P, I, I, I, P], I),
+    "cg_l1_bwd": ([P, I, P, I, P, I, P, I, F, I, I, I, P], I),
+    "cg_centroid_bwd": ([P, I, P, I, P, I, P, I, P, I, F, I, I, I, P], I),
+    "cg_fm_bwd": ([P, I, P, P, P, I, F, I, I, I, P], I),
+    "cg_gloss_finalize": ([P, P, P, P, P, C.POINTER(GlossDesc), P], I),
+    "cg_sum_parts": ([P, P, P, P, P, I, P], I),
+    "cg_adam_amsgrad": ([P, P, P, P, P, Z, P, F, F, F, P, P], I),
+    "cg_attn_ln_fwd": ([P, P, P, P, I, I, I, P], I),
+    "cg_attn_bwd_blocks": ([I], I),
+    "cg_attn_ln_bwd": ([P, P, P, P, P, P, P, I, I, I, I, P], I),
+}
+
+_lib = None
+
+
+def load():
+    """Returns the loaded library with argtypes set; raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python cycle-gan-rna_amd/build.py` "
+            "(this package has no CPU or PyTorch fallback for its kernels)")
+    lib = C.CDLL(LIB_PATH)
+    for name, (argtypes, restype) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = restype
+    _lib = lib
+    return lib
+
+
+class CgError(RuntimeError):
+    pass
+
+
+def check(status: int, what: str):
+    if status != 0:
+        kind = {-1: "bad argument", -2: "unsupported", -3: "workspace too small"}.get(status, f"hipError {status}")
+        raise CgError(f"{what}: {kind}")

@@ -1,0 +1,214 @@
+// Train-mode BatchNorm1d (forward, backward, backward-of-backward) fused with
+// the activation / dropout that follows it.  HBM/L2-bound column kernels: a
+// block owns a strip of 32 columns (one 128-byte line per row) and walks the M
+// rows with 8 row lanes; column statistics are accumulated in float64 and
+// combined across the row lanes through LDS, then the same block applies them.
+#include "common.h"
+
+namespace {
+
+constexpr int CW = 32;   // columns per block
+constexpr int RL = 8;    // row lanes per block
+
+// Sum `NS` per-thread doubles over the 8 row lanes of each column.
+template <int NS>
+__device__ __forceinline__ void strip_reduce(double (&s)[NS], double* lds /* NS*RL*CW */) {
+  const int c = threadIdx.x & (CW - 1), r = threadIdx.x / CW;
+#pragma unroll
+  for (int i = 0; i < NS; ++i) lds[(i * RL + r) * CW + c] = s[i];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    double a = 0.0;
+#pragma unroll
+    for (int rr = 0; rr < RL; ++rr) a += lds[(i * RL + rr) * CW + c];
+    s[i] = a;
+  }
+  __syncthreads();
+}
+
+__global__ void __launch_bounds__(256) bn_fwd_kernel(float* Y, int ldy, const float* X, int ldx, int M, int N,
+                                                     const float* gamma, const float* beta, float eps,
+                                                     float* mean_out, float* invstd_out, float* rmean, float* rvar,
+                                                     float momentum, float slope, const float* mask, int ldmask,
+                                                     float* pm_out, int ldpm, u16* ybf, int ldybf) {
+  __shared__ double lds[2 * RL * CW];
+  const int c = threadIdx.x & (CW - 1), r0 = threadIdx.x / CW;
+  const int col = blockIdx.x * CW + c;
+  const bool ok = col < N;
+  double s[2] = {0.0, 0.0};
+  if (ok)
+    for (int m = r0; m < M; m += RL) {
+      const double x = X[(size_t)m * ldx + col];
+      s[0] += x;
+      s[1] += x * x;
+    }
+  strip_reduce<2>(s, lds);
+  const double mean_d = s[0] / M;
+  double var_d = s[1] / M - mean_d * mean_d;
+  if (var_d < 0.0) var_d = 0.0;
+  const float mean = (float)mean_d;
+  const float invstd = (float)(1.0 / sqrt(var_d + (double)eps));
+  if (ok && r0 == 0) {
+    mean_out[col] = mean;
+    invstd_out[col] = invstd;
+    if (rmean) rmean[col] = (1.f - momentum) * rmean[col] + momentum * mean;
+    if (rvar) {
+      const float unb = (float)(var_d * ((double)M / (double)(M > 1 ? M - 1 : 1)));
+      rvar[col] = (1.f - momentum) * rvar[col] + momentum * unb;
+    }
+  }
+  if (!ok) return;
+  const float ga = gamma[col], be = beta[col];
+  for (int m = r0; m < M; m += RL) {
+    const float xh = (X[(size_t)m * ldx + col] - mean) * invstd;
+    const float h = xh * ga + be;
+    float pm = h > 0.f ? 1.f : slope;
+    if (mask) pm *= mask[(size_t)m * ldmask + col];
+    const float y = h * pm;
+    Y[(size_t)m * ldy + col] = y;
+    if (pm_out) pm_out[(size_t)m * ldpm + col] = pm;
+    if (ybf) ybf[(size_t)m * ldybf + col] = f2bf(y);
+  }
+}
+
+__global__ void __launch_bounds__(256) bn_eval_kernel(float* Y, int ldy, const float* X, int ldx, int M, int N,
+                                                      const float* gamma, const float* beta, const float* rmean,
+                                                      const float* rvar, float eps, float slope) {
+  const int c = threadIdx.x & (CW - 1), r0 = threadIdx.x / CW;
+  const int col = blockIdx.x * CW + c;
+  if (col >= N) return;
+  const float mean = rmean[col], invstd = 1.f / sqrtf(rvar[col] + eps), ga = gamma[col], be = beta[col];
+  for (int m = blockIdx.y * RL + r0; m < M; m += RL * gridDim.y) {
+    const float h = (X[(size_t)m * ldx + col] - mean) * invstd * ga + be;
+    Y[(size_t)m * ldy + col] = h > 0.f ? h : h * slope;
+  }
+}
+
+__device__ __forceinline__ float pm_of(const float* Y, int ldy, const float* PM, int ldpm, float slope, int m, int col) {
+  if (PM) return PM[(size_t)m * ldpm + col];
+  if (Y) return Y[(size_t)m * ldy + col] > 0.f ? 1.f : slope;
+  return 1.f;
+}
+
+__global__ void __launch_bounds__(256) bn_bwd_kernel(float* dX, int lddx, const float* dY, int lddy, const float* X,
+                                                     int ldx, const float* Y, int ldy, const float* PM, int ldpm,
+                                                     const float* mean, const float* invstd, const float* gamma,
+                                                     float* dgamma, float* dbeta, int accumulate, float* gbar_out,
+                                                     float* gxbar_out, float slope, int M, int N) {
+  __shared__ double lds[2 * RL * CW];
+  const int c = threadIdx.x & (CW - 1), r0 = threadIdx.x / CW;
+  const int col = blockIdx.x * CW + c;
+  const bool ok = col < N;
+  const float mu = ok ? mean[col] : 0.f, is = ok ? invstd[col] : 0.f;
+  double s[2] = {0.0, 0.0};
+  if (ok)
+    for (int m = r0; m < M; m += RL) {
+      const float g = dY[(size_t)m * lddy + col] * pm_of(Y, ldy, PM, ldpm, slope, m, col);
+      const float xh = (X[(size_t)m * ldx + col] - mu) * is;
+      s[0] += g;
+      s[1] += (double)g * xh;
+    }
+  strip_reduce<2>(s, lds);
+  if (!ok) return;
+  const float gbar = (float)(s[0] / M), gxbar = (float)(s[1] / M);
+  if (r0 == 0) {
+    if (dbeta) dbeta[col] = (accumulate ? dbeta[col] : 0.f) + (float)s[0];
+    if (dgamma) dgamma[col] = (accumulate ? dgamma[col] : 0.f) + (float)s[1];
+    if (gbar_out) gbar_out[col] = gbar;
+    if (gxbar_out) gxbar_out[col] = gxbar;
+  }
+  const float k = is * gamma[col];
+  for (int m = r0; m < M; m += RL) {
+    const float g = dY[(size_t)m * lddy + col] * pm_of(Y, ldy, PM, ldpm, slope, m, col);
+    const float xh = (X[(size_t)m * ldx + col] - mu) * is;
+    dX[(size_t)m * lddx + col] = k * (g - gbar - xh * gxbar);
+  }
+}
+
+__global__ void __launch_bounds__(256) bn_bwd_bwd_kernel(float* Vu, int ldvu, float* Vh, int ldvh, float* dgamma,
+                                                         int accumulate, const float* W, int ldw, const float* U1,
+                                                         int ldu, const float* X, int ldx, const float* mean,
+                                                         const float* invstd, const float* gamma, const float* ubar,
+                                                         const float* mbar, int M, int N) {
+  __shared__ double lds[3 * RL * CW];
+  const int c = threadIdx.x & (CW - 1), r0 = threadIdx.x / CW;
+  const int col = blockIdx.x * CW + c;
+  const bool ok = col < N;
+  const float mu = ok ? mean[col] : 0.f, is = ok ? invstd[col] : 0.f;
+  double s[3] = {0.0, 0.0, 0.0};
+  if (ok)
+    for (int m = r0; m < M; m += RL) {
+      const float w = W[(size_t)m * ldw + col];
+      const float xh = (X[(size_t)m * ldx + col] - mu) * is;
+      s[0] += w;
+      s[1] += (double)w * xh;
+      s[2] += (double)w * U1[(size_t)m * ldu + col];
+    }
+  strip_reduce<3>(s, lds);
+  if (!ok) return;
+  const float wbar = (float)(s[0] / M), r = (float)(s[1] / M), q = (float)(s[2] / M);
+  const float ub = ubar[col], mb = mbar[col], ga = gamma[col];
+  if (r0 == 0 && dgamma) {
+    const float d = (float)((double)M * is * ((double)q - (double)wbar * ub - (double)r * mb));
+    dgamma[col] = (accumulate ? dgamma[col] : 0.f) + d;
+  }
+  const float k1 = is * ga, k2 = -is * is * ga, k3 = q - wbar * ub - 3.f * mb * r;
+  for (int m = r0; m < M; m += RL) {
+    const float w = W[(size_t)m * ldw + col];
+    const float u1 = U1[(size_t)m * ldu + col];
+    const float xh = (X[(size_t)m * ldx + col] - mu) * is;
+    Vu[(size_t)m * ldvu + col] = k1 * (w - wbar - xh * r);
+    Vh[(size_t)m * ldvh + col] = k2 * (mb * (w - wbar) + r * (u1 - ub) + xh * k3);
+  }
+}
+
+}  // namespace
+
+extern "C" int cg_bn_fwd(float* Y, int ldy, const float* X, int ldx, int M, int N, const float* gamma,
+                         const float* beta, float eps, float* mean_out, float* invstd_out, float* running_mean,
+                         float* running_var, float momentum, float slope, const float* mask, int ldmask,
+                         float* pm_out, int ldpm, void* ybf16, int ldybf16, void* stream) {
+  if (!Y || !X || !gamma || !beta || !mean_out || !invstd_out || M <= 0 || N <= 0) return CG_ERR_BAD_ARG;
+  if (ldy < N || ldx < N || (mask && ldmask < N) || (pm_out && ldpm < N) || (ybf16 && ldybf16 < N)) return CG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(bn_fwd_kernel, dim3((N + CW - 1) / CW), dim3(256), 0, (hipStream_t)stream, Y, ldy, X, ldx, M, N,
+                     gamma, beta, eps, mean_out, invstd_out, running_mean, running_var, momentum, slope, mask, ldmask,
+                     pm_out, ldpm, (u16*)ybf16, ldybf16);
+  return cg_launch_status();
+}
+
+extern "C" int cg_bn_eval(float* Y, int ldy, const float* X, int ldx, int M, int N, const float* gamma,
+                          const float* beta, const float* running_mean, const float* running_var, float eps,
+                          float slope, void* stream) {
+  if (!Y || !X || !gamma || !beta || !running_mean || !running_var || M <= 0 || N <= 0) return CG_ERR_BAD_ARG;
+  if (ldy < N || ldx < N) return CG_ERR_BAD_ARG;
+  int gy = (M + RL * 16 - 1) / (RL * 16);
+  if (gy > 64) gy = 64;
+  hipLaunchKernelGGL(bn_eval_kernel, dim3((N + CW - 1) / CW, gy), dim3(256), 0, (hipStream_t)stream, Y, ldy, X, ldx,
+                     M, N, gamma, beta, running_mean, running_var, eps, slope);
+  return cg_launch_status();
+}
+
+extern "C" int cg_bn_bwd(float* dX, int lddx, const float* dY, int lddy, const float* X, int ldx, const float* Y,
+                         int ldy, const float* PM, int ldpm, const float* mean, const float* invstd,
+                         const float* gamma, float* dgamma, float* dbeta, int accumulate, float* gbar_out,
+                         float* gxbar_out, float slope, int M, int N, void* stream) {
+  if (!dX || !dY || !X || !mean || !invstd || !gamma || M <= 0 || N <= 0) return CG_ERR_BAD_ARG;
+  if (lddx < N || lddy < N || ldx < N || (Y && ldy < N) || (PM && ldpm < N)) return CG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(bn_bwd_kernel, dim3((N + CW - 1) / CW), dim3(256), 0, (hipStream_t)stream, dX, lddx, dY, lddy, X,
+                     ldx, Y, ldy, PM, ldpm, mean, invstd, gamma, dgamma, dbeta, accumulate, gbar_out, gxbar_out, slope,
+                     M, N);
+  return cg_launch_status();
+}
+
+extern "C" int cg_bn_bwd_bwd(float* V_u1, int ldvu, float* V_h0, int ldvh, float* dgamma, int accumulate,
+                             const float* W, int ldw, const float* U1, int ldu, const float* X, int ldx,
+                             const float* mean, const float* invstd, const float* gamma, const float* ubar,
+                             const float* mbar, int M, int N, void* stream) {
+  if (!V_u1 || !V_h0 || !W || !U1 || !X || !mean || !invstd || !gamma || !ubar || !mbar || M <= 0 || N <= 0)
+    return CG_ERR_BAD_ARG;
+  if (ldvu < N || ldvh < N || ldw < N || ldu < N || ldx < N) return CG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(bn_bwd_bwd_kernel, dim3((N + CW - 1) / CW), dim3(256), 0, (hipStream_t)stream, V_u1, ldvu, V_h0,
+                     ldvh, dgamma, accumulate, W, ldw, U1, ldu, X, ldx, mean, invstd, gamma, ubar, mbar, M, N);
+  return cg_launch_status();
+}

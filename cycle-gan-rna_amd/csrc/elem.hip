@@ -1,0 +1,536 @@
+// Elementwise, gather/scatter and reduction kernels of the training step.
+// All are HBM/L2-bound; threads run along the contiguous (column) dimension,
+// grid.y strides over rows.  Reductions write one float partial per block
+// (at most CG_MAX_PARTS) and the consumer adds them in index order in float64,
+// so every loss is reproducible run to run (no float atomics).
+#include "common.h"
+
+namespace {
+
+struct Grid2 {
+  dim3 grid, block;
+};
+static inline Grid2 grid2(int M, int N, int max_blocks = 2048) {
+  int gx = (N + 255) / 256;
+  int gy = M;
+  if (gy > max_blocks / gx) gy = max_blocks / gx;
+  if (gy < 1) gy = 1;
+  return {dim3(gx, gy), dim3(256)};
+}
+static inline Grid2 grid_red(int M, int N) { return grid2(M, N, CG_MAX_PARTS); }
+
+#define CG_2D_LOOP(M, N)                                  \
+  const int col = blockIdx.x * 256 + threadIdx.x;         \
+  if (col < (N))                                          \
+    for (int m = blockIdx.y; m < (M); m += gridDim.y)
+
+__global__ void axpby_kernel(float* out, int ldo, float a, const float* x, int ldx, float b, const float* y, int ldy,
+                             int M, int N) {
+  CG_2D_LOOP(M, N) {
+    float v = a * x[(size_t)m * ldx + col];
+    if (y) v += b * y[(size_t)m * ldy + col];
+    out[(size_t)m * ldo + col] = v;
+  }
+}
+
+__global__ void mul_kernel(float* out, int ldo, const float* x, int ldx, const float* y, int ldy, int M, int N) {
+  CG_2D_LOOP(M, N) out[(size_t)m * ldo + col] = x[(size_t)m * ldx + col] * y[(size_t)m * ldy + col];
+}
+
+__global__ void fill_coef_kernel(float* out, int ldo, int M, int N, const float* coef, int idx, float scale) {
+  const float v = coef[idx] * scale;
+  CG_2D_LOOP(M, N) out[(size_t)m * ldo + col] = v;
+}
+
+__global__ void to_bf16_kernel(u16* out, int ldo, const float* x, int ldx, int M, int N) {
+  CG_2D_LOOP(M, N) out[(size_t)m * ldo + col] = f2bf(x[(size_t)m * ldx + col]);
+}
+
+__global__ void embed_gather_kernel(float* out, int ldo, const float* table, int E, const int64_t* labels,
+                                    int lstride, int M, int n_types) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * E) return;
+  const int m = i / E, e = i % E;
+  int64_t t = labels[(size_t)m * lstride];
+  t = t < 0 ? 0 : (t >= n_types ? n_types - 1 : t);
+  out[(size_t)m * ldo + e] = table[t * E + e];
+}
+
+// One thread per table entry walks all rows: deterministic, and the table is tiny.
+__global__ void embed_scatter_kernel(float* dtable, int E, const float* dout, int lddo, const int64_t* labels,
+                                     int lstride, int M, int n_types, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_types * E) return;
+  const int t = i / E, e = i % E;
+  float s = 0.f;
+  for (int m = 0; m < M; ++m)
+    if (labels[(size_t)m * lstride] == t) s += dout[(size_t)m * lddo + e];
+  dtable[i] = (accumulate ? dtable[i] : 0.f) + s;
+}
+
+__global__ void reparam_fwd_kernel(float* z, int ldz, const float* ml, int ldml, const float* eps, int M, int L) {
+  CG_2D_LOOP(M, L) {
+    const float mu = ml[(size_t)m * ldml + col], lv = ml[(size_t)m * ldml + L + col];
+    z[(size_t)m * ldz + col] = mu + eps[(size_t)m * L + col] * expf(0.5f * lv);
+  }
+}
+
+__global__ void reparam_bwd_kernel(float* dml, int ldd, const float* dz, int lddz, const float* ml, int ldml,
+                                   const float* eps, const float* coef, int kl_idx, float kl_weight, int M, int L) {
+  // kl = -0.5*mean(1 + lv - mu^2 - exp(lv)): d/dmu = mu/n, d/dlv = -0.5*(1-exp(lv))/n, n = M*L
+  const float k = coef ? coef[kl_idx] * kl_weight / ((float)M * (float)L) : 0.f;
+  CG_2D_LOOP(M, L) {
+    const float mu = ml[(size_t)m * ldml + col], lv = ml[(size_t)m * ldml + L + col];
+    const float g = dz[(size_t)m * lddz + col];
+    const float std = expf(0.5f * lv);
+    dml[(size_t)m * ldd + col] = g + k * mu;
+    dml[(size_t)m * ldd + L + col] = g * eps[(size_t)m * L + col] * 0.5f * std + k * (-0.5f) * (1.f - expf(lv));
+  }
+}
+
+// One block per row.
+__global__ void __launch_bounds__(256) libsize_fwd_kernel(float* Y, int ldy, const float* X, int ldx, float* rowsum,
+                                                          float lib, int N) {
+  __shared__ float lds[17];
+  const int m = blockIdx.x;
+  float s = 0.f;
+  for (int c = threadIdx.x; c < N; c += 256) s += fmaxf(X[(size_t)m * ldx + c], 0.f);
+  s = block_sum<float>(s, lds, true);
+  if (threadIdx.x == 0) rowsum[m] = s;
+  const float k = lib / (s + 1e-10f);
+  for (int c = threadIdx.x; c < N; c += 256) Y[(size_t)m * ldy + c] = fmaxf(X[(size_t)m * ldx + c], 0.f) * k;
+}
+
+__global__ void __launch_bounds__(256) libsize_bwd_kernel(float* dX, int lddx, const float* dY, int lddy,
+                                                          const float* X, int ldx, const float* rowsum, float lib,
+                                                          int N) {
+  __shared__ float lds[17];
+  const int m = blockIdx.x;
+  float s = 0.f;
+  for (int c = threadIdx.x; c < N; c += 256) s += dY[(size_t)m * lddy + c] * fmaxf(X[(size_t)m * ldx + c], 0.f);
+  s = block_sum<float>(s, lds, true);
+  const float den = rowsum[m] + 1e-10f;
+  const float k = lib / den, t = s / den;
+  for (int c = threadIdx.x; c < N; c += 256) {
+    const float x = X[(size_t)m * ldx + c];
+    dX[(size_t)m * lddx + c] = x > 0.f ? k * (dY[(size_t)m * lddy + c] - t) : 0.f;
+  }
+}
+
+__global__ void gp_interp_kernel(float* out, int ldo, const float* real, int ldr, const float* fake, int ldf,
+                                 const float* alpha, int M, int G) {
+  CG_2D_LOOP(M, G) {
+    const float a = alpha[m];
+    out[(size_t)m * ldo + col] = a * real[(size_t)m * ldr + col] + (1.f - a) * fake[(size_t)m * ldf + col];
+  }
+}
+
+__global__ void __launch_bounds__(256) gp_penalty_kernel(float* V, int ldv, float* rowpen, const float* UX, int ldu,
+                                                         float lam2_over_m, int G) {
+  __shared__ float lds[17];
+  const int m = blockIdx.x;
+  float s = 0.f;
+  for (int c = threadIdx.x; c < G; c += 256) {
+    const float u = UX[(size_t)m * ldu + c];
+    s += u * u;
+  }
+  s = block_sum<float>(s, lds, true);
+  const float n = sqrtf(s);
+  if (threadIdx.x == 0) rowpen[m] = (n - 1.f) * (n - 1.f);
+  // d/du of (n-1)^2 is 2 (n-1) u / n; torch's norm backward yields 0 at n = 0
+  const float k = n > 0.f ? lam2_over_m * (n - 1.f) / n : 0.f;
+  for (int c = threadIdx.x; c < G; c += 256) V[(size_t)m * ldv + c] = k * UX[(size_t)m * ldu + c];
+}
+
+// ---- reductions ----------------------------------------------------------- //
+__device__ __forceinline__ void write_part(float v, float* parts, int* nparts) {
+  __shared__ float lds[17];
+  v = block_sum<float>(v, lds);
+  if (threadIdx.x == 0) {
+    parts[blockIdx.y * gridDim.x + blockIdx.x] = v;
+    if (blockIdx.x == 0 && blockIdx.y == 0) *nparts = gridDim.x * gridDim.y;
+  }
+}
+
+__global__ void __launch_bounds__(256) reduce_sum_kernel(float* parts, int* nparts, const float* X, int ldx, int M,
+                                                         int N) {
+  float s = 0.f;
+  CG_2D_LOOP(M, N) s += X[(size_t)m * ldx + col];
+  write_part(s, parts, nparts);
+}
+
+__global__ void __launch_bounds__(256) reduce_l1_kernel(float* parts, int* nparts, const float* A, int lda,
+                                                        const float* B, int ldb, int M, int N) {
+  float s = 0.f;
+  CG_2D_LOOP(M, N) s += fabsf(A[(size_t)m * lda + col] - B[(size_t)m * ldb + col]);
+  write_part(s, parts, nparts);
+}
+
+__global__ void __launch_bounds__(256) reduce_centroid_kernel(float* parts, int* nparts, const float* A, int lda,
+                                                              const float* Cn, int ldc, const int64_t* labels,
+                                                              int lstride, int M, int N) {
+  float s = 0.f;
+  CG_2D_LOOP(M, N) {
+    const float d = A[(size_t)m * lda + col] - Cn[(size_t)labels[(size_t)m * lstride] * ldc + col];
+    s += d * d;
+  }
+  write_part(s, parts, nparts);
+}
+
+__global__ void __launch_bounds__(256) reduce_sqdiff_kernel(float* parts, int* nparts, const float* A, int lda,
+                                                            const float* B, int ldb, int M, int N) {
+  float s = 0.f;
+  CG_2D_LOOP(M, N) {
+    const float d = A[(size_t)m * lda + col] - B[(size_t)m * ldb + col];
+    s += d * d;
+  }
+  write_part(s, parts, nparts);
+}
+
+__global__ void __launch_bounds__(256) reduce_kl_kernel(float* parts, int* nparts, const float* ml, int ldml, int M,
+                                                        int L) {
+  float s = 0.f;
+  CG_2D_LOOP(M, L) {
+    const float mu = ml[(size_t)m * ldml + col], lv = ml[(size_t)m * ldml + L + col];
+    s += 1.f + lv - mu * mu - expf(lv);
+  }
+  write_part(s, parts, nparts);
+}
+
+// Column statistics with the 32-column strip layout of bn.hip.
+__global__ void __launch_bounds__(256) colsum_kernel(float* out, const float* X, int ldx, int M, int N, float scale,
+                                                     int accumulate) {
+  __shared__ double lds[8 * 32];
+  const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + c;
+  double s = 0.0;
+  if (col < N)
+    for (int m = r0; m < M; m += 8) s += X[(size_t)m * ldx + col];
+  lds[r0 * 32 + c] = s;
+  __syncthreads();
+  if (r0 == 0 && col < N) {
+    double a = 0.0;
+    for (int r = 0; r < 8; ++r) a += lds[r * 32 + c];
+    out[col] = (accumulate ? out[col] : 0.f) + (float)(a * (double)scale);
+  }
+}
+
+// Per-strip sum of unbiased column variances -> parts; finalised by colvar_final.
+__global__ void __launch_bounds__(256) colvar_kernel(double* parts, const float* X, int ldx, int M, int N) {
+  __shared__ double lds[2 * 8 * 32];
+  const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + c;
+  double s = 0.0, q = 0.0;
+  if (col < N)
+    for (int m = r0; m < M; m += 8) {
+      const double x = X[(size_t)m * ldx + col];
+      s += x;
+      q += x * x;
+    }
+  lds[r0 * 32 + c] = s;
+  lds[256 + r0 * 32 + c] = q;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    double var = 0.0;
+    if (col < N) {
+      double a = 0.0, b = 0.0;
+      for (int r = 0; r < 8; ++r) {
+        a += lds[r * 32 + c];
+        b += lds[256 + r * 32 + c];
+      }
+      const double mean = a / M;
+      var = (b - M * mean * mean) / (M > 1 ? M - 1 : 1);
+    }
+    for (int o = 16; o > 0; o >>= 1) var += __shfl_xor(var, o, 64);
+    if (threadIdx.x == 0) parts[blockIdx.x] = var;
+  }
+}
+__global__ void colvar_final_kernel(float* out, const double* parts, int nstrips, int N) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < nstrips; ++i) s += parts[i];
+    out[0] = (float)(s / N);
+  }
+}
+
+__global__ void l1_bwd_kernel(float* dA, int ldd, const float* A, int lda, const float* B, int ldb, const float* coef,
+                              int idx, float scale, int M, int N, int accumulate) {
+  const float k = coef[idx] * scale;
+  CG_2D_LOOP(M, N) {
+    const float d = A[(size_t)m * lda + col] - B[(size_t)m * ldb + col];
+    const float g = d > 0.f ? k : (d < 0.f ? -k : 0.f);
+    float* o = dA + (size_t)m * ldd + col;
+    *o = accumulate ? *o + g : g;
+  }
+}
+
+__global__ void centroid_bwd_kernel(float* dA, int ldd, const float* A, int lda, const float* Cn, int ldc,
+                                    const int64_t* labels, int lstride, const float* coef, int idx, float scale, int M,
+                                    int N, int accumulate) {
+  const float k = coef[idx] * scale;
+  CG_2D_LOOP(M, N) {
+    const float g = k * (A[(size_t)m * lda + col] - Cn[(size_t)labels[(size_t)m * lstride] * ldc + col]);
+    float* o = dA + (size_t)m * ldd + col;
+    *o = accumulate ? *o + g : g;
+  }
+}
+
+__global__ void fm_bwd_kernel(float* dF, int ldd, const float* mf, const float* mr, const float* coef, int idx,
+                              float scale, int M, int N, int accumulate) {
+  const float k = coef[idx] * scale;
+  CG_2D_LOOP(M, N) {
+    const float g = k * (mf[col] - mr[col]);
+    float* o = dF + (size_t)m * ldd + col;
+    *o = accumulate ? *o + g : g;
+  }
+}
+
+// ---- loss bookkeeping (float64, one thread: a few hundred adds) ------------ //
+__device__ double sum_slot(const float* parts, const int* nparts, int slot) {
+  double s = 0.0;
+  const int n = nparts[slot];
+  const float* p = parts + (size_t)slot * CG_MAX_PARTS;
+  for (int i = 0; i < n && i < CG_MAX_PARTS; ++i) s += (double)p[i];
+  return s;
+}
+
+__global__ void gloss_finalize_kernel(double* ema, double* losses, float* coef, const float* parts, const int* nparts,
+                                      cg_gloss_desc d) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double L[5];
+  for (int k = 0; k < 5; ++k) {
+    // each term is rounded to float32 like the tensor the reference calls .item() on
+    float acc = 0.f;
+    for (int j = 0; j < d.n_terms[k]; ++j) acc = acc + (float)(d.weight[k][j] * sum_slot(parts, nparts, d.slot[k][j]));
+    L[k] = (double)acc;
+  }
+  const double a = d.ema_alpha;
+  double sc[5];
+  for (int k = 0; k < 5; ++k) ema[k] = a * L[k] + (1.0 - a) * ema[k];
+  sc[0] = 1.0 / (fabs(ema[0]) + 1e-8);
+  for (int k = 1; k < 5; ++k) sc[k] = 1.0 / (ema[k] + 1e-8);
+  double mn = sc[0];
+  for (int k = 1; k < 5; ++k) mn = sc[k] < mn ? sc[k] : mn;
+  double g = 0.0;
+  for (int k = 0; k < 5; ++k) {
+    sc[k] /= mn;
+    const double c = d.lambda[k] * sc[k];
+    coef[k] = (float)c;
+    g += c * L[k];
+    losses[k] = L[k];
+    losses[6 + k] = sc[k];
+  }
+  losses[5] = g;
+}
+
+__global__ void sum_parts_kernel(double* totals, const float* parts, const int* nparts, const int* slots,
+                                 const double* scales, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) totals[i] = scales[i] * sum_slot(parts, nparts, slots[i]);
+}
+
+}  // namespace
+
+#define ST ((hipStream_t)stream)
+
+extern "C" int cg_axpby(float* out, int ldo, float a, const float* x, int ldx, float b, const float* y, int ldy, int M,
+                        int N, void* stream) {
+  if (!out || !x || M < 0 || N < 0 || ldo < N || ldx < N || (y && ldy < N)) return CG_ERR_BAD_ARG;
+  if (M == 0 || N == 0) return CG_OK;
+  Grid2 g = grid2(M, N);
+  hipLaunchKernelGGL(axpby_kernel, g.grid, g.block, 0, ST, out, ldo, a, x, ldx, b, y, ldy, M, N);
+  return cg_launch_status();
+}
+
+extern "C" int cg_mul(float* out, int ldo, const float* x, int ldx, const float* y, int ldy, int M, int N,
+                      void* stream) {
+  if (!out || !x || !y || M < 0 || N < 0 || ldo < N || ldx < N || ldy < N) return CG_ERR_BAD_ARG;
+  if (M == 0 || N == 0) return CG_OK;
+  Grid2 g = grid2(M, N);
+  hipLaunchKernelGGL(mul_kernel, g.grid, g.block, 0, ST, out, ldo, x, ldx, y, ldy, M, N);
+  return cg_launch_status();
+}
+
+extern "C" int cg_fill_coef(float* out, int ldo, int M, int N, const float* coef, int idx, float scale, void* stream) {
+  if (!out || !coef || M < 0 || N < 0 || ldo < N || idx < 0) return CG_ERR_BAD_ARG;
+  if (M == 0 || N == 0) return CG_OK;
+  Grid2 g = grid2(M, N);
+  hipLaunchKernelGGL(fill_coef_kernel, g.grid, g.block, 0, ST, out, ldo, M, N, coef, idx, scale);
+  return cg_launch_status();
+}
+
+extern "C" int cg_to_bf16(void* out, int ldo, const float* x, int ldx, int M, int N, void* stream) {
+  if (!out || !x || M < 0 || N < 0 || ldo < N || ldx < N) return CG_ERR_BAD_ARG;
+  if (M == 0 || N == 0) return CG_OK;
+  Grid2 g = grid2(M, N);
+  hipLaunchKernelGGL(to_bf16_kernel, g.grid, g.block, 0, ST, (u16*)out, ldo, x, ldx, M, N);
+  return cg_launch_status();
+}
+
+extern "C" int cg_embed_gather(float* out, int ldo, const float* table, int E, const int64_t* labels, int lstride,
+                               int M, int n_types, void* stream) {
+  if (!out || !table || !labels || E <= 0 || M < 0 || ldo < E || lstride < 1 || n_types <= 0) return CG_ERR_BAD_ARG;
+  if (M == 0) return CG_OK;
+  hipLaunchKernelGGL(embed_gather_kernel, dim3((M * E + 255) / 256), dim3(256), 0, ST, out, ldo, table, E, labels,
+                     lstride, M, n_types);
+  return cg_launch_status();
+}
+
+extern "C" int cg_embed_scatter(float* dtable, int E, const float* dout, int lddo, const int64_t* labels, int lstride,
+                                int M, int n_types, int accumulate, void* stream) {
+  if (!dtable || !dout || !labels || E <= 0 || M < 0 || lddo < E || lstride < 1 || n_types <= 0) return CG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(embed_scatter_kernel, dim3((n_types * E + 63) / 64), dim3(64), 0, ST, dtable, E, dout, lddo,
+                     labels, lstride, M, n_types, accumulate);
+  return cg_launch_status();
+}
+
+extern "C" int cg_reparam_fwd(float* z, int ldz, const float* ml, int ldml, const float* eps, int M, int L,
+                              void* stream) {
+  if (!z || !ml || !eps || M <= 0 || L <= 0 || ldz < L || ldml < 2 * L) return CG_ERR_BAD_ARG;
+  Grid2 g = grid2(M, L);
+  hipLaunchKernelGGL(reparam_fwd_kernel, g.grid, g.block, 0, ST, z, ldz, ml, ldml, eps, M, L);
+  return cg_launch_status();
+}
+
+extern "C" int cg_reparam_bwd(float* dml, int ldd, const float* dz, int lddz, const float* ml, int ldml,
+                              const float* eps, const float* coef, int kl_idx, float kl_weight, int M, int L,
+                              void* stream) {
+  if (!dml || !dz || !ml || !eps || M <= 0 || L <= 0 || ldd < 2 * L || lddz < L || ldml < 2 * L) return CG_ERR_BAD_ARG;
+  Grid2 g = grid2(M, L);
+  hipLaunchKernelGGL(reparam_bwd_kernel, g.grid, g.block, 0, ST, dml, ldd, dz, lddz, ml, ldml, eps, coef, kl_idx,
+                     kl_weight, M, L);
+  return cg_launch_status();
+}
+
+extern "C" int cg_libsize_fwd(float* Y, int ldy, const float* X, int ldx, float* rowsum, float library_size, int M,
+                              int N, void* stream) {
+  if (!Y || !X || !rowsum || M <= 0 || N <= 0 || ldy < N || ldx < N) return CG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(libsize_fwd_kernel, dim3(M), dim3(256), 0, ST, Y, ldy, X, ldx, rowsum, library_size, N);
+  return cg_launch_status();
+}
+
+extern "C" int cg_libsize_bwd(float* dX, int lddx, const float* dY, int lddy, const float* X, int ldx,
+                              const float* rowsum, float library_size, int M, int N, void* stream) {
+  if (!dX || !dY || !X || !rowsum || M <= 0 || N <= 0 || lddx < N || lddy < N || ldx < N) return CG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(libsize_bwd_kernel, dim3(M), dim3(256), 0, ST, dX, lddx, dY, lddy, X, ldx, rowsum, library_size,
+                     N);
+  return cg_launch_status();
+}
+
+extern "C" int cg_gp_interp(float* out, int ldo, const float* real, int ldr, const float* fake, int ldf,
+                            const float* alpha, int M, int G, void* stream) {
+  if (!out || !real || !fake || !alpha || M <= 0 || G <= 0 || ldo < G || ldr < G || ldf < G) return CG_ERR_BAD_ARG;
+  Grid2 g = grid2(M, G);
+  hipLaunchKernelGGL(gp_interp_kernel, g.grid, g.block, 0, ST, out, ldo, real, ldr, fake, ldf, alpha, M, G);
+  return cg_launch_status();
+}
+
+extern "C" int cg_gp_penalty(float* V, int ldv, float* rowpen, const float* UX, int ldu, float lambda_gp, int M, int G,
+                             void* stream) {
+  if (!V || !rowpen || !UX || M <= 0 || G <= 0 || ldv < G || ldu < G) return CG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(gp_penalty_kernel, dim3(M), dim3(256), 0, ST, V, ldv, rowpen, UX, ldu, lambda_gp * 2.f / (float)M,
+                     G);
+  return cg_launch_status();
+}
+
+extern "C" int cg_reduce_sum(float* parts, int* nparts, const float* X, int ldx, int M, int N, void* stream) {
+  if (!parts || !nparts || !X || M <= 0 || N <= 0 || ldx < N) return CG_ERR_BAD_ARG;
+  Grid2 g = grid_red(M, N);
+  hipLaunchKernelGGL(reduce_sum_kernel, g.grid, g.block, 0, ST, parts, nparts, X, ldx, M, N);
+  return cg_launch_status();
+}
+
+extern "C" int cg_reduce_l1(float* parts, int* nparts, const float* A, int lda, const float* B, int ldb, int M, int N,
+                            void* stream) {
+  if (!parts || !nparts || !A || !B || M <= 0 || N <= 0 || lda < N || ldb < N) return CG_ERR_BAD_ARG;
+  Grid2 g = grid_red(M, N);
+  hipLaunchKernelGGL(reduce_l1_kernel, g.grid, g.block, 0, ST, parts, nparts, A, lda, B, ldb, M, N);
+  return cg_launch_status();
+}
+
+extern "C" int cg_reduce_centroid_sq(float* parts, int* nparts, const float* A, int lda, const float* Cn, int ldc,
+                                     const int64_t* labels, int lstride, int M, int N, void* stream) {
+  if (!parts || !nparts || !A || !Cn || !labels || M <= 0 || N <= 0 || lda < N || ldc < N || lstride < 1)
+    return CG_ERR_BAD_ARG;
+  Grid2 g = grid_red(M, N);
+  hipLaunchKernelGGL(reduce_centroid_kernel, g.grid, g.block, 0, ST, parts, nparts, A, lda, Cn, ldc, labels, lstride, M,
+                     N);
+  return cg_launch_status();
+}
+
+extern "C" int cg_reduce_kl(float* parts, int* nparts, const float* ml, int ldml, int M, int L, void* stream) {
+  if (!parts || !nparts || !ml || M <= 0 || L <= 0 || ldml < 2 * L) return CG_ERR_BAD_ARG;
+  Grid2 g = grid_red(M, L);
+  hipLaunchKernelGGL(reduce_kl_kernel, g.grid, g.block, 0, ST, parts, nparts, ml, ldml, M, L);
+  return cg_launch_status();
+}
+
+extern "C" int cg_colsum(float* out, const float* X, int ldx, int M, int N, float scale, int accumulate,
+                         void* stream) {
+  if (!out || !X || M <= 0 || N <= 0 || ldx < N) return CG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 31) / 32), dim3(256), 0, ST, out, X, ldx, M, N, scale, accumulate);
+  return cg_launch_status();
+}
+
+extern "C" int cg_reduce_sqdiff(float* parts, int* nparts, const float* A, int lda, const float* B, int ldb, int M,
+                                int N, void* stream) {
+  if (!parts || !nparts || !A || !B || M <= 0 || N <= 0 || lda < N || ldb < N) return CG_ERR_BAD_ARG;
+  Grid2 g = grid_red(M, N);
+  hipLaunchKernelGGL(reduce_sqdiff_kernel, g.grid, g.block, 0, ST, parts, nparts, A, lda, B, ldb, M, N);
+  return cg_launch_status();
+}
+
+extern "C" int cg_colvar_mean(float* out, double* strip_ws, const float* X, int ldx, int M, int N, void* stream) {
+  if (!out || !strip_ws || !X || M <= 0 || N <= 0 || ldx < N) return CG_ERR_BAD_ARG;
+  const int ns = (N + 31) / 32;
+  hipLaunchKernelGGL(colvar_kernel, dim3(ns), dim3(256), 0, ST, strip_ws, X, ldx, M, N);
+  hipLaunchKernelGGL(colvar_final_kernel, dim3(1), dim3(64), 0, ST, out, strip_ws, ns, N);
+  return cg_launch_status();
+}
+
+extern "C" int cg_l1_bwd(float* dA, int ldd, const float* A, int lda, const float* B, int ldb, const float* coef,
+                         int idx, float scale, int M, int N, int accumulate, void* stream) {
+  if (!dA || !A || !B || !coef || M <= 0 || N <= 0 || ldd < N || lda < N || ldb < N) return CG_ERR_BAD_ARG;
+  Grid2 g = grid2(M, N);
+  hipLaunchKernelGGL(l1_bwd_kernel, g.grid, g.block, 0, ST, dA, ldd, A, lda, B, ldb, coef, idx, scale, M, N,
+                     accumulate);
+  return cg_launch_status();
+}
+
+extern "C" int cg_centroid_bwd(float* dA, int ldd, const float* A, int lda, const float* Cn, int ldc,
+                               const int64_t* labels, int lstride, const float* coef, int idx, float scale, int M,
+                               int N, int accumulate, void* stream) {
+  if (!dA || !A || !Cn || !labels || !coef || M <= 0 || N <= 0 || ldd < N || lda < N || ldc < N) return CG_ERR_BAD_ARG;
+  Grid2 g = grid2(M, N);
+  hipLaunchKernelGGL(centroid_bwd_kernel, g.grid, g.block, 0, ST, dA, ldd, A, lda, Cn, ldc, labels, lstride, coef, idx,
+                     scale, M, N, accumulate);
+  return cg_launch_status();
+}
+
+extern "C" int cg_fm_bwd(float* dF, int ldd, const float* mean_fake, const float* mean_real, const float* coef, int idx,
+                         float scale, int M, int N, int accumulate, void* stream) {
+  if (!dF || !mean_fake || !mean_real || !coef || M <= 0 || N <= 0 || ldd < N) return CG_ERR_BAD_ARG;
+  Grid2 g = grid2(M, N);
+  hipLaunchKernelGGL(fm_bwd_kernel, g.grid, g.block, 0, ST, dF, ldd, mean_fake, mean_real, coef, idx, scale, M, N,
+                     accumulate);
+  return cg_launch_status();
+}
+
+extern "C" int cg_gloss_finalize(double* ema_state, double* losses_out, float* coef_out, const float* parts,
+                                 const int* nparts, const cg_gloss_desc* desc, void* stream) {
+  if (!ema_state || !losses_out || !coef_out || !parts || !nparts || !desc) return CG_ERR_BAD_ARG;
+  for (int k = 0; k < 5; ++k)
+    if (desc->n_terms[k] < 0 || desc->n_terms[k] > 4) return CG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(gloss_finalize_kernel, dim3(1), dim3(64), 0, ST, ema_state, losses_out, coef_out, parts, nparts,
+                     *desc);
+  return cg_launch_status();
+}
+
+extern "C" int cg_sum_parts(double* totals, const float* parts, const int* nparts, const int* slots,
+                            const double* scales, int n, void* stream) {
+  if (!totals || !parts || !nparts || !slots || !scales || n <= 0) return CG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(sum_parts_kernel, dim3((n + 63) / 64), dim3(64), 0, ST, totals, parts, nparts, slots, scales, n);
+  return cg_launch_status();
+}
+
+extern "C" int cg_version(void) { return 100; }

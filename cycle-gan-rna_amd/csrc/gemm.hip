@@ -1,0 +1,247 @@
+// MFMA GEMM for gfx950: C[M,N] (+)= op(A)[M,K] * op(B)[K,N], float32 accumulate.
+//
+// float32 path: v_mfma_f32_32x32x2_f32 (exact float32 products, k-ordered fmaf
+// chain).  256 threads = 4 waves laid out 2x2 over a BM x BN block tile, each
+// wave owning (BM/2) x (BN/2) as 32x32 MFMA tiles.  Tiles are staged
+// global -> registers -> LDS, double-buffered over K in slabs of BK = 32.
+//
+// An operand whose reduction index is contiguous in memory ("k-major": A with
+// transA=0, B with transB=1) is kept in LDS as [row][BK+4] and read with one
+// ds_read_b128 per four MFMA k-steps; an operand whose reduction index is the
+// slow one ("m-major") is kept as [k][rows+4] and read with ds_read_b32.  The
+// 32x32x2 MFMA consumes two k values per step (lane half h = lane>>5 supplies
+// one of them); both operands use k = 8c + 4h + s for step s of group c, so the
+// sum covers every k exactly once whatever the storage.
+#include "common.h"
+
+namespace {
+
+struct GemmArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  const float* bias;
+  const float* E;
+  float* aux;
+  int M, N, K, lda, ldb, ldc, lde, ldaux;
+  int epi, accumulate;
+  float slope;
+  int tiles_n;
+};
+
+constexpr int BK = 32;
+
+// Guarded 4-element load along the contiguous dimension.
+template <bool VEC>
+__device__ __forceinline__ f32x4 load4(const float* p, bool outer_ok, int c0, int climit) {
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (!outer_ok) return v;
+  if (VEC && c0 + 3 < climit) {
+    v = *reinterpret_cast<const f32x4*>(p);
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (c0 + e < climit) v[e] = p[e];
+  }
+  return v;
+}
+
+// Stage registers for one operand tile of ROWS x BK.
+//  k-major: element (r,k) = ptr[(row0+r)*ld + k0+k]
+//  m-major: element (r,k) = ptr[(k0+k)*ld + row0+r]
+template <int ROWS, bool MMAJ, bool VEC>
+struct Stager {
+  static constexpr int NV = ROWS * BK / 4 / 256;  // float4 per thread
+  f32x4 v[NV];
+
+  __device__ __forceinline__ void load(const float* ptr, int ld, int row0, int nrows, int k0, int K) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int idx = t + 256 * j;
+      if (!MMAJ) {
+        const int r = idx / (BK / 4), kq = idx % (BK / 4);
+        const int row = row0 + r, k = k0 + 4 * kq;
+        v[j] = load4<VEC>(ptr + (size_t)row * ld + k, row < nrows, k, K);
+      } else {
+        const int k = idx / (ROWS / 4), rq = idx % (ROWS / 4);
+        const int row = row0 + 4 * rq, kk = k0 + k;
+        v[j] = load4<VEC>(ptr + (size_t)kk * ld + row, kk < K, row, nrows);
+      }
+    }
+  }
+  __device__ __forceinline__ void store(float* s) const {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int idx = t + 256 * j;
+      if (!MMAJ) {
+        const int r = idx / (BK / 4), kq = idx % (BK / 4);
+        *reinterpret_cast<f32x4*>(s + r * (BK + 4) + 4 * kq) = v[j];
+      } else {
+        const int k = idx / (ROWS / 4), rq = idx % (ROWS / 4);
+        *reinterpret_cast<f32x4*>(s + k * (ROWS + 4) + 4 * rq) = v[j];
+      }
+    }
+  }
+};
+
+template <int BM, int BN, bool TA, bool TB, bool VEC>
+__global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr bool A_MMAJ = TA, B_MMAJ = !TB;
+  constexpr int A_ELEMS = A_MMAJ ? BK * (BM + 4) : BM * (BK + 4);
+  constexpr int B_ELEMS = B_MMAJ ? BK * (BN + 4) : BN * (BK + 4);
+  __shared__ __align__(16) float smem[2 * (A_ELEMS + B_ELEMS)];
+
+  const int tile = blockIdx.x;
+  const int bm = (tile / g.tiles_n) * BM, bn = (tile % g.tiles_n) * BN;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
+  const int li = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  Stager<BM, A_MMAJ, VEC> sa;
+  Stager<BN, B_MMAJ, VEC> sb;
+  const int nk = (g.K + BK - 1) / BK;
+
+  sa.load(g.A, g.lda, bm, g.M, 0, g.K);
+  sb.load(g.B, g.ldb, bn, g.N, 0, g.K);
+  sa.store(smem);
+  sb.store(smem + A_ELEMS);
+  __syncthreads();
+
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) {
+      sa.load(g.A, g.lda, bm, g.M, (kt + 1) * BK, g.K);
+      sb.load(g.B, g.ldb, bn, g.N, (kt + 1) * BK, g.K);
+    }
+    const float* As = smem + cur * (A_ELEMS + B_ELEMS);
+    const float* Bs = As + A_ELEMS;
+#pragma unroll
+    for (int c = 0; c < BK / 8; ++c) {
+      float a[TM][4], b[TN][4];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if (!A_MMAJ) {
+          f32x4 t = *reinterpret_cast<const f32x4*>(As + (wm + 32 * i + li) * (BK + 4) + 8 * c + 4 * lh);
+          a[i][0] = t[0]; a[i][1] = t[1]; a[i][2] = t[2]; a[i][3] = t[3];
+        } else {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) a[i][s] = As[(8 * c + 4 * lh + s) * (BM + 4) + wm + 32 * i + li];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        if (!B_MMAJ) {
+          f32x4 t = *reinterpret_cast<const f32x4*>(Bs + (wn + 32 * j + li) * (BK + 4) + 8 * c + 4 * lh);
+          b[j][0] = t[0]; b[j][1] = t[1]; b[j][2] = t[2]; b[j][3] = t[3];
+        } else {
+#pragma unroll
+          for (int s = 0; s < 4; ++s) b[j][s] = Bs[(8 * c + 4 * lh + s) * (BN + 4) + wn + 32 * j + li];
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      float* nxt = smem + (cur ^ 1) * (A_ELEMS + B_ELEMS);
+      sa.store(nxt);
+      sb.store(nxt + A_ELEMS);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // epilogue: 32x32 accumulator, col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = bn + wn + 32 * j + li;
+      if (col >= g.N) continue;
+      const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = bm + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row >= g.M) continue;
+        float h = acc[i][j][r] + bv;
+        float* cp = g.C + (size_t)row * g.ldc + col;
+        if (g.epi == CG_EPI_NONE) {
+          if (g.accumulate) h += *cp;
+          *cp = h;
+        } else if (g.epi == CG_EPI_LEAKY) {
+          float pm = h > 0.f ? 1.f : g.slope;
+          if (g.E) pm *= g.E[(size_t)row * g.lde + col];
+          *cp = h * pm;
+          if (g.aux) g.aux[(size_t)row * g.ldaux + col] = pm;
+        } else {
+          *cp = h * g.E[(size_t)row * g.lde + col];
+        }
+      }
+    }
+}
+
+template <int BM, int BN>
+int launch_f32(const GemmArgs& g, int transA, int transB, bool vec, hipStream_t st) {
+  GemmArgs a = g;
+  const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
+  a.tiles_n = tn;
+  dim3 grid(tm * tn), block(256);
+#define CG_LAUNCH(TA, TB)                                                              \
+  do {                                                                                 \
+    if (vec)                                                                           \
+      hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, true>), grid, block, 0, st, a);  \
+    else                                                                               \
+      hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, false>), grid, block, 0, st, a); \
+  } while (0)
+  if (!transA && transB) CG_LAUNCH(false, true);
+  else if (!transA && !transB) CG_LAUNCH(false, false);
+  else if (transA && !transB) CG_LAUNCH(true, false);
+  else CG_LAUNCH(true, true);
+#undef CG_LAUNCH
+  return cg_launch_status();
+}
+
+}  // namespace
+
+extern "C" int cg_gemm(float* C, int ldc, const void* A, int lda, const void* B, int ldb,
+                       int M, int N, int K, int transA, int transB, int dtype,
+                       const float* bias, int epi, const float* E, int lde, float* aux, int ldaux,
+                       float slope, int accumulate, void* stream) {
+  if (!C || !A || !B || M < 0 || N < 0 || K < 0) return CG_ERR_BAD_ARG;
+  if (M == 0 || N == 0) return CG_OK;
+  if (epi < CG_EPI_NONE || epi > CG_EPI_MUL) return CG_ERR_BAD_ARG;
+  if (epi == CG_EPI_MUL && !E) return CG_ERR_BAD_ARG;
+  if (epi != CG_EPI_NONE && accumulate) return CG_ERR_BAD_ARG;
+  const int a_rows = transA ? K : M, a_cols = transA ? M : K;
+  const int b_rows = transB ? N : K, b_cols = transB ? K : N;
+  (void)a_rows; (void)b_rows;
+  if (lda < a_cols || ldb < b_cols || ldc < N) return CG_ERR_BAD_ARG;
+  if (E && lde < N) return CG_ERR_BAD_ARG;
+  if (aux && ldaux < N) return CG_ERR_BAD_ARG;
+  if (dtype != CG_F32) return CG_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  GemmArgs g{(const float*)A, (const float*)B, C, bias, E, aux, M, N, K, lda, ldb, ldc, lde, ldaux,
+             epi, accumulate, slope, 0};
+  const bool vec = (((uintptr_t)A | (uintptr_t)B) % 16 == 0) && (lda % 4 == 0) && (ldb % 4 == 0);
+  // Tile choice: the largest tile that still yields about one block per CU.
+  const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
+  const long t12864 = (long)((M + 127) / 128) * ((N + 63) / 64);
+  if (t128 >= 192) return launch_f32<128, 128>(g, transA, transB, vec, st);
+  if (t12864 >= 192) return launch_f32<128, 64>(g, transA, transB, vec, st);
+  return launch_f32<64, 64>(g, transA, transB, vec, st);
+}

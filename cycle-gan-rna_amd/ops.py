@@ -1,0 +1,309 @@
+"""Tensor-level wrappers over the C ABI of libcgrna.so.
+
+Each method takes torch tensors that already live in HBM, checks shapes on the
+host (a kernel is never launched on operands that do not match what its grid
+assumes), and enqueues one kernel on torch's current HIP stream.  torch is only
+the owner of the memory and the stream here; no torch arithmetic runs in this
+file, and there is no fallback when the library or the GPU is missing.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+EPI_NONE, EPI_LEAKY, EPI_MUL = 0, 1, 2
+MAX_PARTS = 1024
+ATTN_NPARAM = 48 * 16 + 48 + 16 * 16 + 16 + 16 + 16
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _ld(t):
+    """Leading dimension of a 2-D row-major view (or of a vector seen as one row)."""
+    if t is None:
+        return 0
+    if t.dim() == 1:
+        return t.shape[0]
+    assert t.dim() == 2 and (t.stride(1) == 1 or t.shape[1] == 1), (t.shape, t.stride())
+    return t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1])
+
+
+def _chk(t, dtype=torch.float32):
+    assert t.is_cuda and t.dtype == dtype, (t.device, t.dtype)
+
+
+class HipOps:
+    """The product backend: every method is one or two HIP kernel launches."""
+
+    name = "hip"
+
+    def __init__(self, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("cycle-gan-rna_amd needs a HIP device (torch.cuda.is_available() is False)")
+        self.lib = _lib.load()
+        self.device = torch.device(device if device is not None else "cuda:0")
+
+    # -- plumbing -------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def empty(self, *shape, dtype=torch.float32):
+        return torch.empty(*shape, dtype=dtype, device=self.device)
+
+    def zeros(self, *shape, dtype=torch.float32):
+        return torch.zeros(*shape, dtype=dtype, device=self.device)
+
+    def to_device(self, t):
+        return t.to(self.device)
+
+    # -- GEMM -----------------------------------------------------------------
+    def gemm(self, Cm, A, B, transA=False, transB=False, bias=None, epi=EPI_NONE, E=None, aux=None, slope=0.0,
+             accumulate=False):
+        _chk(Cm), _chk(A), _chk(B)
+        M, N = Cm.shape
+        K = A.shape[0] if transA else A.shape[1]
+        assert (A.shape[1] if transA else A.shape[0]) == M, (A.shape, Cm.shape, transA)
+        assert (B.shape[0] if transB else B.shape[1]) == N and (B.shape[1] if transB else B.shape[0]) == K, \
+            (A.shape, B.shape, Cm.shape, transA, transB)
+        if bias is not None:
+            assert bias.numel() == N
+        if E is not None:
+            assert tuple(E.shape) == (M, N)
+        if aux is not None:
+            assert tuple(aux.shape) == (M, N)
+        st = self.lib.cg_gemm(_ptr(Cm), _ld(Cm), _ptr(A), _ld(A), _ptr(B), _ld(B), M, N, K, int(transA), int(transB),
+                              0, _ptr(bias), epi, _ptr(E), _ld(E), _ptr(aux), _ld(aux), float(slope),
+                              int(accumulate), self._stream())
+        _lib.check(st, "cg_gemm")
+
+    # -- BatchNorm --------------------------------------------------------------
+    def bn_fwd(self, Y, X, gamma, beta, mean, invstd, rmean, rvar, slope, mask=None, pm=None, eps=1e-5,
+               momentum=0.1):
+        M, N = X.shape
+        assert Y.shape == X.shape and gamma.numel() == N and mean.numel() == N and invstd.numel() == N
+        st = self.lib.cg_bn_fwd(_ptr(Y), _ld(Y), _ptr(X), _ld(X), M, N, _ptr(gamma), _ptr(beta), eps, _ptr(mean),
+                                _ptr(invstd), _ptr(rmean), _ptr(rvar), momentum, float(slope), _ptr(mask), _ld(mask),
+                                _ptr(pm), _ld(pm), None, 0, self._stream())
+        _lib.check(st, "cg_bn_fwd")
+
+    def bn_eval(self, Y, X, gamma, beta, rmean, rvar, slope, eps=1e-5):
+        M, N = X.shape
+        st = self.lib.cg_bn_eval(_ptr(Y), _ld(Y), _ptr(X), _ld(X), M, N, _ptr(gamma), _ptr(beta), _ptr(rmean),
+                                 _ptr(rvar), eps, float(slope), self._stream())
+        _lib.check(st, "cg_bn_eval")
+
+    def bn_bwd(self, dX, dY, X, Y, PM, mean, invstd, gamma, dgamma, dbeta, accumulate, slope, gbar=None, gxbar=None):
+        M, N = X.shape
+        assert dX.shape == X.shape and dY.shape == X.shape
+        st = self.lib.cg_bn_bwd(_ptr(dX), _ld(dX), _ptr(dY), _ld(dY), _ptr(X), _ld(X), _ptr(Y), _ld(Y), _ptr(PM),
+                                _ld(PM), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(dgamma), _ptr(dbeta),
+                                int(accumulate), _ptr(gbar), _ptr(gxbar), float(slope), M, N, self._stream())
+        _lib.check(st, "cg_bn_bwd")
+
+    def bn_bwd_bwd(self, Vu, Vh, dgamma, accumulate, W, U1, X, mean, invstd, gamma, ubar, mbar):
+        M, N = X.shape
+        assert Vu.shape == X.shape and Vh.shape == X.shape and W.shape == X.shape and U1.shape == X.shape
+        st = self.lib.cg_bn_bwd_bwd(_ptr(Vu), _ld(Vu), _ptr(Vh), _ld(Vh), _ptr(dgamma), int(accumulate), _ptr(W),
+                                    _ld(W), _ptr(U1), _ld(U1), _ptr(X), _ld(X), _ptr(mean), _ptr(invstd), _ptr(gamma),
+                                    _ptr(ubar), _ptr(mbar), M, N, self._stream())
+        _lib.check(st, "cg_bn_bwd_bwd")
+
+    # -- elementwise ------------------------------------------------------------
+    def axpby(self, out, a, x, b=0.0, y=None):
+        M, N = out.shape
+        assert x.shape == out.shape and (y is None or y.shape == out.shape)
+        st = self.lib.cg_axpby(_ptr(out), _ld(out), float(a), _ptr(x), _ld(x), float(b), _ptr(y), _ld(y), M, N,
+                               self._stream())
+        _lib.check(st, "cg_axpby")
+
+    def mul(self, out, x, y):
+        M, N = out.shape
+        assert x.shape == out.shape and y.shape == out.shape
+        st = self.lib.cg_mul(_ptr(out), _ld(out), _ptr(x), _ld(x), _ptr(y), _ld(y), M, N, self._stream())
+        _lib.check(st, "cg_mul")
+
+    def fill_coef(self, out, coef, idx, scale):
+        M, N = out.shape
+        st = self.lib.cg_fill_coef(_ptr(out), _ld(out), M, N, _ptr(coef), idx, float(scale), self._stream())
+        _lib.check(st, "cg_fill_coef")
+
+    def embed_gather(self, out, table, labels):
+        M = out.shape[0]
+        n_types, E = table.shape
+        _chk(labels, torch.int64)
+        assert out.shape[1] == E and labels.shape[0] == M and table.is_contiguous()
+        st = self.lib.cg_embed_gather(_ptr(out), _ld(out), _ptr(table), E, _ptr(labels), labels.stride(0), M, n_types,
+                                      self._stream())
+        _lib.check(st, "cg_embed_gather")
+
+    def embed_scatter(self, dtable, dout, labels, accumulate):
+        n_types, E = dtable.shape
+        M = dout.shape[0]
+        assert dout.shape[1] == E and labels.shape[0] == M and dtable.is_contiguous()
+        st = self.lib.cg_embed_scatter(_ptr(dtable), E, _ptr(dout), _ld(dout), _ptr(labels), labels.stride(0), M,
+                                       n_types, int(accumulate), self._stream())
+        _lib.check(st, "cg_embed_scatter")
+
+    def reparam_fwd(self, z, ml, eps):
+        M, L = z.shape
+        assert ml.shape == (M, 2 * L) and eps.shape == (M, L) and eps.is_contiguous()
+        st = self.lib.cg_reparam_fwd(_ptr(z), _ld(z), _ptr(ml), _ld(ml), _ptr(eps), M, L, self._stream())
+        _lib.check(st, "cg_reparam_fwd")
+
+    def reparam_bwd(self, dml, dz, ml, eps, coef, kl_idx, kl_weight):
+        M, L = dz.shape
+        assert dml.shape == (M, 2 * L) and ml.shape == (M, 2 * L) and eps.shape == (M, L)
+        st = self.lib.cg_reparam_bwd(_ptr(dml), _ld(dml), _ptr(dz), _ld(dz), _ptr(ml), _ld(ml), _ptr(eps), _ptr(coef),
+                                     kl_idx, float(kl_weight), M, L, self._stream())
+        _lib.check(st, "cg_reparam_bwd")
+
+    def libsize_fwd(self, Y, X, rowsum, lib):
+        M, N = X.shape
+        assert Y.shape == X.shape and rowsum.numel() == M
+        st = self.lib.cg_libsize_fwd(_ptr(Y), _ld(Y), _ptr(X), _ld(X), _ptr(rowsum), float(lib), M, N, self._stream())
+        _lib.check(st, "cg_libsize_fwd")
+
+    def libsize_bwd(self, dX, dY, X, rowsum, lib):
+        M, N = X.shape
+        st = self.lib.cg_libsize_bwd(_ptr(dX), _ld(dX), _ptr(dY), _ld(dY), _ptr(X), _ld(X), _ptr(rowsum), float(lib),
+                                     M, N, self._stream())
+        _lib.check(st, "cg_libsize_bwd")
+
+    def gp_interp(self, out, real, fake, alpha):
+        M, G = out.shape
+        assert real.shape == out.shape and fake.shape == out.shape and alpha.numel() == M
+        st = self.lib.cg_gp_interp(_ptr(out), _ld(out), _ptr(real), _ld(real), _ptr(fake), _ld(fake), _ptr(alpha), M,
+                                   G, self._stream())
+        _lib.check(st, "cg_gp_interp")
+
+    def gp_penalty(self, V, rowpen, UX, lambda_gp):
+        M, G = UX.shape
+        assert V.shape == UX.shape and rowpen.numel() == M
+        st = self.lib.cg_gp_penalty(_ptr(V), _ld(V), _ptr(rowpen), _ptr(UX), _ld(UX), float(lambda_gp), M, G,
+                                    self._stream())
+        _lib.check(st, "cg_gp_penalty")
+
+    # -- reductions ---------------------------------------------------------------
+    # `red` = (parts [n_slots, MAX_PARTS] float32, nparts [n_slots] int32); slot picks the row.
+    def _slot(self, red, slot):
+        parts, nparts = red
+        return (C.c_void_p(parts.data_ptr() + slot * MAX_PARTS * 4), C.c_void_p(nparts.data_ptr() + slot * 4))
+
+    def reduce_sum(self, red, slot, X):
+        X2 = X if X.dim() == 2 else X.view(1, -1)
+        p, n = self._slot(red, slot)
+        st = self.lib.cg_reduce_sum(p, n, _ptr(X2), _ld(X2), X2.shape[0], X2.shape[1], self._stream())
+        _lib.check(st, "cg_reduce_sum")
+
+    def reduce_l1(self, red, slot, A, B):
+        assert A.shape == B.shape
+        p, n = self._slot(red, slot)
+        st = self.lib.cg_reduce_l1(p, n, _ptr(A), _ld(A), _ptr(B), _ld(B), A.shape[0], A.shape[1], self._stream())
+        _lib.check(st, "cg_reduce_l1")
+
+    def reduce_sqdiff(self, red, slot, A, B):
+        A2, B2 = (A, B) if A.dim() == 2 else (A.view(1, -1), B.view(1, -1))
+        p, n = self._slot(red, slot)
+        st = self.lib.cg_reduce_sqdiff(p, n, _ptr(A2), _ld(A2), _ptr(B2), _ld(B2), A2.shape[0], A2.shape[1],
+                                       self._stream())
+        _lib.check(st, "cg_reduce_sqdiff")
+
+    def reduce_centroid_sq(self, red, slot, A, Cn, labels):
+        assert Cn.shape[1] == A.shape[1] and labels.shape[0] == A.shape[0]
+        p, n = self._slot(red, slot)
+        st = self.lib.cg_reduce_centroid_sq(p, n, _ptr(A), _ld(A), _ptr(Cn), _ld(Cn), _ptr(labels), labels.stride(0),
+                                            A.shape[0], A.shape[1], self._stream())
+        _lib.check(st, "cg_reduce_centroid_sq")
+
+    def reduce_kl(self, red, slot, ml):
+        M, L2 = ml.shape
+        p, n = self._slot(red, slot)
+        st = self.lib.cg_reduce_kl(p, n, _ptr(ml), _ld(ml), M, L2 // 2, self._stream())
+        _lib.check(st, "cg_reduce_kl")
+
+    def colsum(self, out, X, scale=1.0, accumulate=False):
+        M, N = X.shape
+        assert out.numel() == N
+        st = self.lib.cg_colsum(_ptr(out), _ptr(X), _ld(X), M, N, float(scale), int(accumulate), self._stream())
+        _lib.check(st, "cg_colsum")
+
+    def colvar_mean(self, out, ws, X):
+        M, N = X.shape
+        assert ws.dtype == torch.float64 and ws.numel() >= (N + 31) // 32
+        st = self.lib.cg_colvar_mean(_ptr(out), _ptr(ws), _ptr(X), _ld(X), M, N, self._stream())
+        _lib.check(st, "cg_colvar_mean")
+
+    def l1_bwd(self, dA, A, B, coef, idx, scale, accumulate=False):
+        M, N = A.shape
+        st = self.lib.cg_l1_bwd(_ptr(dA), _ld(dA), _ptr(A), _ld(A), _ptr(B), _ld(B), _ptr(coef), idx, float(scale), M,
+                                N, int(accumulate), self._stream())
+        _lib.check(st, "cg_l1_bwd")
+
+    def centroid_bwd(self, dA, A, Cn, labels, coef, idx, scale, accumulate=False):
+        M, N = A.shape
+        st = self.lib.cg_centroid_bwd(_ptr(dA), _ld(dA), _ptr(A), _ld(A), _ptr(Cn), _ld(Cn), _ptr(labels),
+                                      labels.stride(0), _ptr(coef), idx, float(scale), M, N, int(accumulate),
+                                      self._stream())
+        _lib.check(st, "cg_centroid_bwd")
+
+    def fm_bwd(self, dF, mean_fake, mean_real, coef, idx, scale, accumulate=False):
+        M, N = dF.shape
+        st = self.lib.cg_fm_bwd(_ptr(dF), _ld(dF), _ptr(mean_fake), _ptr(mean_real), _ptr(coef), idx, float(scale), M,
+                                N, int(accumulate), self._stream())
+        _lib.check(st, "cg_fm_bwd")
+
+    def gloss_finalize(self, ema, losses, coef, red, desc):
+        parts, nparts = red
+        d = _lib.GlossDesc()
+        for k in range(5):
+            terms = desc["terms"][k]
+            d.n_terms[k] = len(terms)
+            for j, (slot, w) in enumerate(terms):
+                d.slot[k][j] = slot
+                d.weight[k][j] = w
+            d.lambda_[k] = desc["lambda"][k]
+        d.ema_alpha = desc["ema_alpha"]
+        assert ema.dtype == torch.float64 and losses.dtype == torch.float64 and losses.numel() >= 11
+        st = self.lib.cg_gloss_finalize(_ptr(ema), _ptr(losses), _ptr(coef), _ptr(parts), _ptr(nparts), C.byref(d),
+                                        self._stream())
+        _lib.check(st, "cg_gloss_finalize")
+
+    def sum_parts(self, totals, red, slots, scales):
+        parts, nparts = red
+        assert totals.dtype == torch.float64 and slots.dtype == torch.int32 and scales.dtype == torch.float64
+        st = self.lib.cg_sum_parts(_ptr(totals), _ptr(parts), _ptr(nparts), _ptr(slots), _ptr(scales), slots.numel(),
+                                   self._stream())
+        _lib.check(st, "cg_sum_parts")
+
+    # -- optimizer ------------------------------------------------------------------
+    def adam(self, p, g, m, v, vmax, lr_step, beta1, beta2, eps):
+        assert lr_step.dtype == torch.float64 and lr_step.numel() == 2
+        n = p.numel()
+        assert g.numel() == n and m.numel() == n and v.numel() == n and vmax.numel() == n
+        st = self.lib.cg_adam_amsgrad(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(vmax), n, _ptr(lr_step), beta1, beta2,
+                                      eps, None, self._stream())
+        _lib.check(st, "cg_adam_amsgrad")
+
+    # -- attention ------------------------------------------------------------------
+    def attn_fwd(self, Y, X, keep, params, heads):
+        n_cells = X.numel() // 256
+        assert X.is_contiguous() and Y.is_contiguous() and params.numel() == ATTN_NPARAM
+        assert keep is None or (keep.is_contiguous() and keep.numel() == n_cells * heads * 256)
+        st = self.lib.cg_attn_ln_fwd(_ptr(Y), _ptr(X), _ptr(keep), _ptr(params), n_cells, 16, heads, self._stream())
+        _lib.check(st, "cg_attn_ln_fwd")
+
+    def attn_bwd_ws(self, n_cells):
+        return self.lib.cg_attn_bwd_blocks(n_cells) * ATTN_NPARAM
+
+    def attn_bwd(self, dX, dparams, ws, dY, X, keep, params, heads, accumulate):
+        n_cells = X.numel() // 256
+        assert ws.numel() >= self.attn_bwd_ws(n_cells) and dparams.numel() == ATTN_NPARAM
+        assert X.is_contiguous() and dY.is_contiguous() and dX.is_contiguous()
+        st = self.lib.cg_attn_ln_bwd(_ptr(dX), _ptr(dparams), _ptr(ws), _ptr(dY), _ptr(X), _ptr(keep), _ptr(params),
+                                     n_cells, 16, heads, int(accumulate), self._stream())
+        _lib.check(st, "cg_attn_ln_bwd")

@@ -1,0 +1,279 @@
+/*
+ * cgrna.h - C ABI of libcgrna.so, the MI355X (gfx950) kernel library behind the
+ * CycleGAN / cycle-cGAN training step.
+ *
+ * The reference (guyshani/cycle-GAN-RNA) has no FFI: its hot path is the Python
+ * API of GAN_functions.py running on aten ops.  Each entry point below is the
+ * device arithmetic of one piece of that path; the comment on each names the
+ * reference lines it replaces.  The Python package binds these with ctypes
+ * (plain pointers and sizes only, no torch types).
+ *
+ * Conventions
+ *   - all matrices are dense row-major float32 unless a parameter says otherwise;
+ *     "ld*" is the leading dimension in elements
+ *   - every pointer is a device pointer owned by the caller; the library never
+ *     allocates, frees or synchronises; work is enqueued on `stream`
+ *     (a hipStream_t passed as void*)
+ *   - return value: 0 on success, CG_ERR_* (negative) for a rejected argument,
+ *     or a positive hipError_t from the launch
+ */
+#ifndef CGRNA_H
+#define CGRNA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CG_OK 0
+#define CG_ERR_BAD_ARG (-1)
+#define CG_ERR_UNSUPPORTED (-2)
+#define CG_ERR_WORKSPACE (-3)
+
+/* GEMM epilogues */
+#define CG_EPI_NONE 0   /* C = acc (+ bias)                                           */
+#define CG_EPI_LEAKY 1  /* h = acc + bias; pm = (h>0 ? 1 : slope) * (E ? E : 1);      */
+                        /* C = h * pm; AUX = pm (if AUX != NULL)                      */
+#define CG_EPI_MUL 2    /* C = (acc + bias) * E                                       */
+
+/* A/B element types of cg_gemm */
+#define CG_F32 0
+#define CG_BF16 1
+
+int cg_version(void);
+
+/* Number of loss-partial slots per reduction (see cg_reduce_*). */
+#define CG_MAX_PARTS 1024
+
+/*
+ * C[M,N] (+)= op(A)[M,K] * op(B)[K,N], float32 accumulate on MFMA.
+ *   transA = 0: A is stored [M][K];  1: A is stored [K][M]
+ *   transB = 0: B is stored [K][N];  1: B is stored [N][K]
+ *   dtype  = CG_F32 (v_mfma_f32_32x32x2_f32, exact float32 products) or
+ *            CG_BF16 (A and B are bf16 bit patterns, v_mfma_f32_16x16x32_bf16)
+ * Replaces nn.Linear forward (GAN_functions.py:59,62,89,92,97-98,117,120,124,
+ * 165,169,172,174; transA=0, transB=1), its input gradient (0,0), its weight
+ * gradient (1,0), and the second-order products of the gradient penalty
+ * (:194-204).  `accumulate` != 0 adds into C (CG_EPI_NONE only).
+ */
+int cg_gemm(float* C, int ldc, const void* A, int lda, const void* B, int ldb,
+            int M, int N, int K, int transA, int transB, int dtype,
+            const float* bias, int epi, const float* E, int lde, float* aux, int ldaux,
+            float slope, int accumulate, void* stream);
+
+/*
+ * Train-mode BatchNorm1d over the M rows of X (GAN_functions.py:60,63,89,93,
+ * 117,121,166) fused with the activation and dropout that follow it
+ * (ReLU :61,89,94,117,122; LeakyReLU(0.2)+Dropout(0.3) :167-168):
+ *   mean, var (biased) per column; xhat = (x-mean)*invstd;
+ *   h = gamma*xhat+beta; pm = (h>0 ? 1 : slope) * (mask ? mask : 1); Y = h*pm
+ * slope = 0 is ReLU, slope = 1 no activation.  mean_out/invstd_out (N) are kept
+ * for the backward; running_mean/running_var (may be NULL) are updated with
+ * `momentum` and the unbiased variance; pm_out (may be NULL) receives pm.
+ * Y may alias X.  ybf16 (may be NULL) receives Y rounded to bf16.
+ */
+int cg_bn_fwd(float* Y, int ldy, const float* X, int ldx, int M, int N,
+              const float* gamma, const float* beta, float eps,
+              float* mean_out, float* invstd_out,
+              float* running_mean, float* running_var, float momentum,
+              float slope, const float* mask, int ldmask, float* pm_out, int ldpm,
+              void* ybf16, int ldybf16, void* stream);
+
+/*
+ * Eval-mode BatchNorm1d + activation (g_m2h.eval() translation pass,
+ * GAN_functions.py:461-468): Y = act(gamma*(x-rm)/sqrt(rv+eps)+beta).
+ */
+int cg_bn_eval(float* Y, int ldy, const float* X, int ldx, int M, int N,
+               const float* gamma, const float* beta, const float* running_mean,
+               const float* running_var, float eps, float slope, void* stream);
+
+/*
+ * Backward of cg_bn_fwd (autograd of the same lines).  g = dY * pm where pm is
+ * PM if given, else (Y>0 ? 1 : slope) from the saved output Y, else 1 (both NULL).
+ *   dbeta (+)= sum_m g;  dgamma (+)= sum_m g*xhat;
+ *   dX = invstd*gamma*(g - mean_m(g) - xhat*mean_m(g*xhat))
+ * dgamma/dbeta may be NULL (input gradient only); `accumulate` adds into them.
+ * gbar_out / gxbar_out (N each, may be NULL) receive mean_m(g), mean_m(g*xhat):
+ * the gradient penalty's second-order pass needs them.  dX may alias dY.
+ */
+int cg_bn_bwd(float* dX, int lddx, const float* dY, int lddy, const float* X, int ldx,
+              const float* Y, int ldy, const float* PM, int ldpm,
+              const float* mean, const float* invstd, const float* gamma,
+              float* dgamma, float* dbeta, int accumulate,
+              float* gbar_out, float* gxbar_out, float slope, int M, int N, void* stream);
+
+/*
+ * BatchNorm backward-of-backward for the gradient penalty
+ * (torch.autograd.grad(..., create_graph=True) then .backward(),
+ * GAN_functions.py:199-203 through :166).  With u1 the first-order gradient
+ * entering the BatchNorm backward, ubar = mean(u1), m = mean(u1*xhat) (from
+ * cg_bn_bwd), and W the incoming second-order gradient w.r.t. u0:
+ *   wbar = mean(W), r = mean(W*xhat), q = mean(W*u1)
+ *   V_u1 = invstd*gamma*(W - wbar - xhat*r)
+ *   V_h0 = -invstd^2*gamma*( m*(W-wbar) + r*(u1-ubar) + xhat*(q - wbar*ubar - 3*m*r) )
+ *   dgamma (+)= M*invstd*(q - wbar*ubar - r*m)
+ */
+int cg_bn_bwd_bwd(float* V_u1, int ldvu, float* V_h0, int ldvh, float* dgamma, int accumulate,
+                  const float* W, int ldw, const float* U1, int ldu, const float* X, int ldx,
+                  const float* mean, const float* invstd, const float* gamma,
+                  const float* ubar, const float* mbar, int M, int N, void* stream);
+
+/* ---- elementwise / gather ------------------------------------------------ */
+
+/* out[i] = a*x[i] + b*y[i]  (y may be NULL); 2-D with leading dimensions. */
+int cg_axpby(float* out, int ldo, float a, const float* x, int ldx, float b, const float* y, int ldy,
+             int M, int N, void* stream);
+/* out = x * y elementwise (2-D). */
+int cg_mul(float* out, int ldo, const float* x, int ldx, const float* y, int ldy, int M, int N, void* stream);
+/* out[m, :] = coef[idx]*scale for all elements (coef is a device array). */
+int cg_fill_coef(float* out, int ldo, int M, int N, const float* coef, int idx, float scale, void* stream);
+/* float32 -> bf16 (round to nearest even), 2-D. */
+int cg_to_bf16(void* out, int ldo, const float* x, int ldx, int M, int N, void* stream);
+
+/* Embedding lookup (GAN_functions.py:135,181): out[m, 0:E] = table[labels[m*lstride], 0:E]. */
+int cg_embed_gather(float* out, int ldo, const float* table, int E, const int64_t* labels, int lstride,
+                    int M, int n_types, void* stream);
+/* Its gradient: dtable[t, e] (+)= sum over rows with label t of dout[m, e] (deterministic order). */
+int cg_embed_scatter(float* dtable, int E, const float* dout, int lddo, const int64_t* labels, int lstride,
+                     int M, int n_types, int accumulate, void* stream);
+
+/*
+ * reparameterize (GAN_functions.py:127-130): z = mu + eps*exp(0.5*log_var).
+ * mu and log_var are the two halves [0:L) and [L:2L) of each row of `ml`
+ * (row stride ldml).
+ */
+int cg_reparam_fwd(float* z, int ldz, const float* ml, int ldml, const float* eps, int M, int L, void* stream);
+/*
+ * Gradient into [dmu | dlog_var] (row stride ldd): from dz through the
+ * reparameterisation plus the KL term of the generator loss
+ * (GAN_functions.py:375-376): kl = -0.5*mean(1 + lv - mu^2 - exp(lv)) scaled by
+ * coef[kl_idx]*kl_weight.
+ */
+int cg_reparam_bwd(float* dml, int ldd, const float* dz, int lddz, const float* ml, int ldml, const float* eps,
+                   const float* coef, int kl_idx, float kl_weight, int M, int L, void* stream);
+
+/* normalize_to_library_size (GAN_functions.py:152-155): y = relu(x)*lib/(sum_row relu(x)+1e-10); rowsum kept. */
+int cg_libsize_fwd(float* Y, int ldy, const float* X, int ldx, float* rowsum, float library_size,
+                   int M, int N, void* stream);
+/* Its backward: dX = [x>0] * s*(dY - sum_row(dY*relu(x))/ (rowsum+1e-10)), s = lib/(rowsum+1e-10). */
+int cg_libsize_bwd(float* dX, int lddx, const float* dY, int lddy, const float* X, int ldx, const float* rowsum,
+                   float library_size, int M, int N, void* stream);
+
+/* ---- gradient penalty pieces (GAN_functions.py:194-204) -------------------- */
+/* interpolates = alpha*real + (1-alpha)*fake, alpha one value per row (:195-196). */
+int cg_gp_interp(float* out, int ldo, const float* real, int ldr, const float* fake, int ldf,
+                 const float* alpha, int M, int G, void* stream);
+/*
+ * Row norms and the penalty (:203): n_m = ||UX[m,:]||_2; rowpen[m] = (n_m-1)^2
+ * (their mean is the penalty); V[m,:] = (lambda*2/M)*((n_m-1)/n_m)*UX[m,:] is the
+ * gradient of lambda*penalty w.r.t. UX.  V may alias UX.
+ */
+int cg_gp_penalty(float* V, int ldv, float* rowpen, const float* UX, int ldu, float lambda_gp,
+                  int M, int G, void* stream);
+
+/* ---- reductions / losses ---------------------------------------------------
+ * Each reduction writes at most CG_MAX_PARTS float partial sums to
+ * `parts` and their count to *nparts (device int); cg_loss_finalize (or any
+ * consumer) adds them in index order in float64, so results are deterministic.
+ */
+/* sum of all elements of X (critic means :330,:335,:347; row-penalty mean :203). */
+int cg_reduce_sum(float* parts, int* nparts, const float* X, int ldx, int M, int N, void* stream);
+/* sum |A - B| (L1 cycle loss :353-357). */
+int cg_reduce_l1(float* parts, int* nparts, const float* A, int lda, const float* B, int ldb, int M, int N, void* stream);
+/* sum (A[m,:] - C[labels[m],:])^2 (cell-type centroid MSE :359-364). */
+int cg_reduce_centroid_sq(float* parts, int* nparts, const float* A, int lda, const float* C, int ldc,
+                          const int64_t* labels, int lstride, int M, int N, void* stream);
+/* sum of (1 + lv - mu^2 - exp(lv)) over [mu | lv] rows (KL :375-376). */
+int cg_reduce_kl(float* parts, int* nparts, const float* ml, int ldml, int M, int L, void* stream);
+/* out[n] (+)= scale * sum_m X[m,n]: column means (feature matching :368,:372; scale = 1/M) and the
+ * bias gradients of nn.Linear (scale = 1). */
+int cg_colsum(float* out, const float* X, int ldx, int M, int N, float scale, int accumulate, void* stream);
+/* sum (A - B)^2 (feature-matching MSE between two mean vectors :368,:372). */
+int cg_reduce_sqdiff(float* parts, int* nparts, const float* A, int lda, const float* B, int ldb, int M, int N,
+                     void* stream);
+/* mean over columns of the unbiased column variance (metrics :418-419), one float;
+ * strip_ws: (N+31)/32 doubles of caller workspace. */
+int cg_colvar_mean(float* out, double* strip_ws, const float* X, int ldx, int M, int N, void* stream);
+
+/* dA = coef[idx]*scale*sign(A-B) (gradient of the L1 term); dA may alias A. */
+int cg_l1_bwd(float* dA, int ldd, const float* A, int lda, const float* B, int ldb,
+              const float* coef, int idx, float scale, int M, int N, int accumulate, void* stream);
+/* dA (+)= coef[idx]*scale*(A[m,:] - C[labels[m],:]) (gradient of the centroid MSE). */
+int cg_centroid_bwd(float* dA, int ldd, const float* A, int lda, const float* C, int ldc,
+                    const int64_t* labels, int lstride, const float* coef, int idx, float scale,
+                    int M, int N, int accumulate, void* stream);
+/* dF[m,n] (+)= coef[idx]*scale*(mf[n]-mr[n]) for every row (gradient of the feature-matching MSE). */
+int cg_fm_bwd(float* dF, int ldd, const float* mean_fake, const float* mean_real,
+              const float* coef, int idx, float scale, int M, int N, int accumulate, void* stream);
+
+/*
+ * Loss bookkeeping of one generator step, on the device in float64 so that no
+ * host round trip sits between the forward and the backward
+ * (GAN_functions.py:347-406).  Inputs are the partial sums written by the
+ * reductions above, laid out as parts[slot*CG_MAX_PARTS + i] with counts
+ * nparts[slot]; slot meaning and normalisation are given by the caller in
+ * `desc` (see cgrna_amd/engine.py).  Updates the five moving averages
+ * (alpha = 0.3), computes the scales, and writes
+ *   losses_out: 11 doubles - g_adv, g_cycle, g_celltype, g_fm, kl, g_loss, then the five scales
+ *   coef_out:   5 floats - lambda_i*scale_i for the backward kernels
+ */
+typedef struct {
+  int n_terms[5];        /* number of (slot, weight) pairs per loss: adv, cycle, celltype, fm, kl */
+  int slot[5][4];
+  double weight[5][4];   /* loss_k = sum_j weight[k][j] * total(slot[k][j]) */
+  double lambda[5];
+  double ema_alpha;
+} cg_gloss_desc;
+int cg_gloss_finalize(double* ema_state, double* losses_out, float* coef_out, const float* parts,
+                      const int* nparts, const cg_gloss_desc* desc, void* stream);
+/* totals[i] = scale[i] * sum(parts[slot i]) for n slots (float64), generic. */
+int cg_sum_parts(double* totals, const float* parts, const int* nparts, const int* slots, const double* scales,
+                 int n, void* stream);
+
+/*
+ * Fused multi-tensor Adam with amsgrad (torch.optim.Adam(..., betas=(0.5,0.9),
+ * amsgrad=True), GAN_functions.py:223-225, stepped at :339-340,:409) over one
+ * flat parameter arena: p, g, m, v, vmax are arrays of n floats.
+ *   m += (1-b1)(g-m); v = b2 v + (1-b2) g^2; vmax = max(vmax, v);
+ *   p -= (lr/(1-b1^t)) * m / (sqrt(vmax)/sqrt(1-b2^t) + eps)
+ * lr_and_step: device array {lr, step t} as two doubles (so captured graphs can
+ * be replayed with a new lr / step).  p_bf16 (may be NULL) receives the updated
+ * parameters rounded to bf16.
+ */
+int cg_adam_amsgrad(float* p, const float* g, float* m, float* v, float* vmax, size_t n,
+                    const double* lr_and_step, float beta1, float beta2, float eps,
+                    void* p_bf16, void* stream);
+
+/*
+ * Fused token self-attention + LayerNorm of the generator bottleneck
+ * (GeneSelfAttention.forward, GAN_functions.py:34-36, with
+ * nn.MultiheadAttention(16, 4, dropout=0.1, batch_first=True) on its
+ * need_weights=True path).  Per cell X is (16 tokens, 16 features), 4 heads:
+ *   qkv = X Win^T + bin; A = softmax(q k^T / 2); P = A * keep;
+ *   o = concat_heads(P v) Wout^T + bout;  Y = LayerNorm(X + o)   (eps 1e-5)
+ * keep (NULL in eval mode) is the dropout keep-mask already divided by 0.9,
+ * laid out (cell*4 + head, 16, 16).  `params` is one block of CG_ATTN_NPARAM
+ * floats: Win[48][16] | bin[48] | Wout[16][16] | bout[16] | ln_w[16] | ln_b[16]
+ * (the order of the module's state_dict).  Only E = 16, heads = 4 is built;
+ * anything else returns CG_ERR_UNSUPPORTED.
+ */
+#define CG_ATTN_NPARAM (48 * 16 + 48 + 16 * 16 + 16 + 16 + 16)
+int cg_attn_ln_fwd(float* Y, const float* X, const float* keep, const float* params, int n_cells, int E, int heads,
+                   void* stream);
+/*
+ * Backward of cg_attn_ln_fwd; the forward is recomputed from X and keep, so no
+ * activations are saved.  dX receives the input gradient; parameter gradients
+ * are summed per workgroup into `wpart` (cg_attn_bwd_blocks(n_cells) x
+ * CG_ATTN_NPARAM floats of caller workspace) and then in workgroup order into
+ * dparams (same layout as params), `accumulate` adding to what is there.
+ */
+int cg_attn_bwd_blocks(int n_cells);
+int cg_attn_ln_bwd(float* dX, float* dparams, float* wpart, const float* dY, const float* X, const float* keep,
+                   const float* params, int n_cells, int E, int heads, int accumulate, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CGRNA_H */

@@ -1,0 +1,306 @@
+"""CPU restatement of every entry point of include/cgrna.h, one method per kernel.
+
+TEST INFRASTRUCTURE ONLY.  `CpuOps` has the method signatures of
+cycle-gan-rna_amd/ops.py:HipOps and computes the same results with plain
+torch-CPU arithmetic (float64 accumulation where the kernels use it).  It has
+two uses, both under tests/: (1) the checker for each HIP kernel on the GPU box,
+(2) a stand-in backend that lets the host-side step engine be exercised, and
+compared with the reference's golden vectors, in a container without a GPU.
+The product never imports this file.
+"""
+from __future__ import annotations
+
+import torch
+
+EPI_NONE, EPI_LEAKY, EPI_MUL = 0, 1, 2
+MAX_PARTS = 1024
+ATTN_NPARAM = 48 * 16 + 48 + 16 * 16 + 16 + 16 + 16
+
+
+class CpuOps:
+    name = "cpu-oracle"
+
+    def __init__(self, dtype=torch.float32):
+        self.device = torch.device("cpu")
+        self.dtype = dtype
+
+    def empty(self, *shape, dtype=None):
+        return torch.empty(*shape, dtype=self._dt(dtype))
+
+    def zeros(self, *shape, dtype=None):
+        return torch.zeros(*shape, dtype=self._dt(dtype))
+
+    def _dt(self, dtype):
+        if dtype is None or dtype == torch.float32:
+            return self.dtype
+        return dtype
+
+    def to_device(self, t):
+        return t.to(self.dtype) if t.is_floating_point() else t
+
+    # -- GEMM (cg_gemm) -----------------------------------------------------------
+    def gemm(self, Cm, A, B, transA=False, transB=False, bias=None, epi=EPI_NONE, E=None, aux=None, slope=0.0,
+             accumulate=False):
+        a = A.t() if transA else A
+        b = B.t() if transB else B
+        h = a @ b
+        if bias is not None:
+            h = h + bias.reshape(1, -1)
+        if epi == EPI_NONE:
+            Cm.copy_(Cm + h if accumulate else h)
+        elif epi == EPI_LEAKY:
+            pm = torch.where(h > 0, torch.ones_like(h), torch.full_like(h, slope))
+            if E is not None:
+                pm = pm * E
+            Cm.copy_(h * pm)
+            if aux is not None:
+                aux.copy_(pm)
+        else:
+            Cm.copy_(h * E)
+
+    # -- BatchNorm (cg_bn_fwd / cg_bn_eval / cg_bn_bwd / cg_bn_bwd_bwd) ------------------
+    def bn_fwd(self, Y, X, gamma, beta, mean, invstd, rmean, rvar, slope, mask=None, pm=None, eps=1e-5,
+               momentum=0.1):
+        M = X.shape[0]
+        xd = X.double()
+        mu = xd.mean(0)
+        var = (xd * xd).mean(0) - mu * mu
+        var = var.clamp_min(0)
+        mean.copy_(mu.to(X.dtype))
+        invstd.copy_((1.0 / torch.sqrt(var + eps)).to(X.dtype))
+        if rmean is not None:
+            rmean.copy_((1 - momentum) * rmean + momentum * mean)
+        if rvar is not None:
+            rvar.copy_((1 - momentum) * rvar + momentum * (var * (M / max(M - 1, 1))).to(X.dtype))
+        h = (X - mean) * invstd * gamma + beta
+        p = torch.where(h > 0, torch.ones_like(h), torch.full_like(h, slope))
+        if mask is not None:
+            p = p * mask
+        Y.copy_(h * p)
+        if pm is not None:
+            pm.copy_(p)
+
+    def bn_eval(self, Y, X, gamma, beta, rmean, rvar, slope, eps=1e-5):
+        h = (X - rmean) * (1.0 / torch.sqrt(rvar + eps)) * gamma + beta
+        Y.copy_(torch.where(h > 0, h, h * slope))
+
+    def _pm(self, X, Y, PM, slope):
+        if PM is not None:
+            return PM
+        if Y is not None:
+            return torch.where(Y > 0, torch.ones_like(Y), torch.full_like(Y, slope))
+        return torch.ones_like(X)
+
+    def bn_bwd(self, dX, dY, X, Y, PM, mean, invstd, gamma, dgamma, dbeta, accumulate, slope, gbar=None, gxbar=None):
+        M = X.shape[0]
+        g = dY * self._pm(X, Y, PM, slope)
+        xh = (X - mean) * invstd
+        s0 = g.double().sum(0)
+        s1 = (g.double() * xh.double()).sum(0)
+        if dbeta is not None:
+            dbeta.copy_((dbeta if accumulate else 0) + s0.to(X.dtype))
+        if dgamma is not None:
+            dgamma.copy_((dgamma if accumulate else 0) + s1.to(X.dtype))
+        gb, gxb = (s0 / M).to(X.dtype), (s1 / M).to(X.dtype)
+        if gbar is not None:
+            gbar.copy_(gb)
+        if gxbar is not None:
+            gxbar.copy_(gxb)
+        dX.copy_(invstd * gamma * (g - gb - xh * gxb))
+
+    def bn_bwd_bwd(self, Vu, Vh, dgamma, accumulate, W, U1, X, mean, invstd, gamma, ubar, mbar):
+        M = X.shape[0]
+        xh = (X - mean) * invstd
+        wbar = (W.double().mean(0)).to(X.dtype)
+        r = ((W.double() * xh.double()).mean(0)).to(X.dtype)
+        q = ((W.double() * U1.double()).mean(0)).to(X.dtype)
+        if dgamma is not None:
+            d = (M * invstd.double() * (q.double() - wbar.double() * ubar.double() - r.double() * mbar.double())).to(X.dtype)
+            dgamma.copy_((dgamma if accumulate else 0) + d)
+        Vu.copy_(invstd * gamma * (W - wbar - xh * r))
+        k3 = q - wbar * ubar - 3.0 * mbar * r
+        Vh.copy_(-invstd * invstd * gamma * (mbar * (W - wbar) + r * (U1 - ubar) + xh * k3))
+
+    # -- elementwise -----------------------------------------------------------------
+    def axpby(self, out, a, x, b=0.0, y=None):
+        out.copy_(a * x if y is None else a * x + b * y)
+
+    def mul(self, out, x, y):
+        out.copy_(x * y)
+
+    def fill_coef(self, out, coef, idx, scale):
+        out.fill_(float(coef[idx]) * scale)
+
+    def embed_gather(self, out, table, labels):
+        out.copy_(table[labels.reshape(labels.shape[0], -1)[:, 0]])
+
+    def embed_scatter(self, dtable, dout, labels, accumulate):
+        lab = labels.reshape(labels.shape[0], -1)[:, 0]
+        acc = torch.zeros_like(dtable)
+        acc.index_add_(0, lab, dout.contiguous())
+        dtable.copy_(dtable + acc if accumulate else acc)
+
+    def reparam_fwd(self, z, ml, eps):
+        L = z.shape[1]
+        z.copy_(ml[:, :L] + eps * torch.exp(0.5 * ml[:, L:]))
+
+    def reparam_bwd(self, dml, dz, ml, eps, coef, kl_idx, kl_weight):
+        M, L = dz.shape
+        k = float(coef[kl_idx]) * kl_weight / (M * L) if coef is not None else 0.0
+        mu, lv = ml[:, :L], ml[:, L:]
+        dml[:, :L] = dz + k * mu
+        dml[:, L:] = dz * eps * 0.5 * torch.exp(0.5 * lv) + k * (-0.5) * (1 - torch.exp(lv))
+
+    def libsize_fwd(self, Y, X, rowsum, lib):
+        r = torch.relu(X)
+        s = r.sum(1)
+        rowsum.copy_(s)
+        Y.copy_(r * (lib / (s[:, None] + 1e-10)))
+
+    def libsize_bwd(self, dX, dY, X, rowsum, lib):
+        r = torch.relu(X)
+        den = rowsum[:, None] + 1e-10
+        t = (dY * r).sum(1, keepdim=True) / den
+        dX.copy_(torch.where(X > 0, (lib / den) * (dY - t), torch.zeros_like(X)))
+
+    def gp_interp(self, out, real, fake, alpha):
+        a = alpha.reshape(-1, 1)
+        out.copy_(a * real + (1 - a) * fake)
+
+    def gp_penalty(self, V, rowpen, UX, lambda_gp):
+        M = UX.shape[0]
+        n = UX.norm(2, dim=1)
+        rowpen.copy_((n - 1) ** 2)
+        k = torch.where(n > 0, (lambda_gp * 2.0 / M) * (n - 1) / n, torch.zeros_like(n))
+        V.copy_(k[:, None] * UX)
+
+    # -- reductions: one partial per "block"; here a single partial -----------------------
+    def _put(self, red, slot, value):
+        parts, nparts = red
+        parts[slot, 0] = value
+        nparts[slot] = 1
+
+    def reduce_sum(self, red, slot, X):
+        self._put(red, slot, X.double().sum())
+
+    def reduce_l1(self, red, slot, A, B):
+        self._put(red, slot, (A - B).abs().double().sum())
+
+    def reduce_sqdiff(self, red, slot, A, B):
+        self._put(red, slot, ((A - B) ** 2).double().sum())
+
+    def reduce_centroid_sq(self, red, slot, A, Cn, labels):
+        lab = labels.reshape(labels.shape[0], -1)[:, 0]
+        self._put(red, slot, ((A - Cn[lab]) ** 2).double().sum())
+
+    def reduce_kl(self, red, slot, ml):
+        L = ml.shape[1] // 2
+        mu, lv = ml[:, :L], ml[:, L:]
+        self._put(red, slot, (1 + lv - mu * mu - torch.exp(lv)).double().sum())
+
+    def colsum(self, out, X, scale=1.0, accumulate=False):
+        s = (X.double().sum(0) * scale).to(X.dtype)
+        out.copy_((out + s.reshape(out.shape)) if accumulate else s.reshape(out.shape))
+
+    def colvar_mean(self, out, ws, X):
+        out.copy_(torch.var(X.double(), dim=0).mean().to(X.dtype).reshape(out.shape))
+
+    def l1_bwd(self, dA, A, B, coef, idx, scale, accumulate=False):
+        g = float(coef[idx]) * scale * torch.sign(A - B)
+        dA.copy_(dA + g if accumulate else g)
+
+    def centroid_bwd(self, dA, A, Cn, labels, coef, idx, scale, accumulate=False):
+        lab = labels.reshape(labels.shape[0], -1)[:, 0]
+        g = float(coef[idx]) * scale * (A - Cn[lab])
+        dA.copy_(dA + g if accumulate else g)
+
+    def fm_bwd(self, dF, mean_fake, mean_real, coef, idx, scale, accumulate=False):
+        g = (float(coef[idx]) * scale * (mean_fake - mean_real)).reshape(1, -1).expand_as(dF)
+        dF.copy_(dF + g if accumulate else g)
+
+    def _slot_total(self, red, slot):
+        parts, nparts = red
+        return float(parts[slot, :int(nparts[slot])].double().sum())
+
+    def gloss_finalize(self, ema, losses, coef, red, desc):
+        L = []
+        for k in range(5):
+            acc = torch.zeros((), dtype=torch.float32)
+            for slot, w in desc["terms"][k]:
+                acc = acc + torch.tensor(w * self._slot_total(red, slot), dtype=torch.float32)
+            L.append(float(acc))
+        a = desc["ema_alpha"]
+        for k in range(5):
+            ema[k] = a * L[k] + (1 - a) * float(ema[k])
+        sc = [1 / (abs(float(ema[0])) + 1e-8)] + [1 / (float(ema[k]) + 1e-8) for k in range(1, 5)]
+        mn = min(sc)
+        sc = [s / mn for s in sc]
+        g = 0.0
+        for k in range(5):
+            c = desc["lambda"][k] * sc[k]
+            coef[k] = c
+            g += c * L[k]
+            losses[k] = L[k]
+            losses[6 + k] = sc[k]
+        losses[5] = g
+
+    def sum_parts(self, totals, red, slots, scales):
+        for i in range(slots.numel()):
+            totals[i] = float(scales[i]) * self._slot_total(red, int(slots[i]))
+
+    # -- Adam (cg_adam_amsgrad) ------------------------------------------------------------
+    def adam(self, p, g, m, v, vmax, lr_step, beta1, beta2, eps):
+        lr, t = float(lr_step[0]), float(lr_step[1])
+        step_size = lr / (1 - beta1 ** t)
+        bc2_sqrt = (1 - beta2 ** t) ** 0.5
+        m.lerp_(g, 1 - beta1)
+        v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+        torch.maximum(vmax, v, out=vmax)
+        denom = (vmax.sqrt() / bc2_sqrt).add_(eps)
+        p.addcdiv_(m, denom, value=-step_size)
+
+    # -- attention + LayerNorm (cg_attn_ln_fwd / cg_attn_ln_bwd) ---------------------------------
+    @staticmethod
+    def _attn_params(params):
+        o = 0
+        out = []
+        for n, shape in ((768, (48, 16)), (48, (48,)), (256, (16, 16)), (16, (16,)), (16, (16,)), (16, (16,))):
+            out.append(params[o:o + n].reshape(shape))
+            o += n
+        return out
+
+    def _attn_forward(self, X, keep, params, heads):
+        Win, bin_, Wout, bout, lnw, lnb = self._attn_params(params)
+        b = X.numel() // 256
+        x = X.reshape(b, 16, 16)
+        hd = 16 // heads
+        qkv = x @ Win.t() + bin_
+        q, k, v = qkv[..., :16], qkv[..., 16:32], qkv[..., 32:]
+
+        def hs(t):
+            return t.reshape(b, 16, heads, hd).permute(0, 2, 1, 3).reshape(b * heads, 16, hd)
+        q, k, v = hs(q) * 0.5, hs(k), hs(v)
+        att = torch.softmax(q @ k.transpose(1, 2), dim=-1)
+        if keep is not None:
+            att = att * keep.reshape(b * heads, 16, 16)
+        o = (att @ v).reshape(b, heads, 16, hd).permute(0, 2, 1, 3).reshape(b, 16, 16)
+        s = x + o @ Wout.t() + bout
+        mean = s.mean(-1, keepdim=True)
+        var = ((s - mean) ** 2).mean(-1, keepdim=True)
+        return (s - mean) * torch.rsqrt(var + 1e-5) * lnw + lnb
+
+    def attn_fwd(self, Y, X, keep, params, heads):
+        Y.copy_(self._attn_forward(X, keep, params, heads).reshape(Y.shape))
+
+    def attn_bwd_ws(self, n_cells):
+        return 1
+
+    def attn_bwd(self, dX, dparams, ws, dY, X, keep, params, heads, accumulate):
+        # the checker differentiates the restated forward; the kernel uses hand-derived formulas
+        with torch.enable_grad():
+            x = X.detach().clone().requires_grad_(True)
+            p = params.detach().clone().requires_grad_(True)
+            y = self._attn_forward(x, keep, p, heads)
+            gx, gp = torch.autograd.grad(y, (x, p), dY.reshape(y.shape))
+        dX.copy_(gx.reshape(dX.shape))
+        dparams.copy_(dparams + gp if accumulate else gp)

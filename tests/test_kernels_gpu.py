@@ -1,0 +1,367 @@
+"""Per-kernel parity on the MI355X: every C-ABI entry point against its CPU
+restatement (oracle/ops_cpu.py) on the same seeded inputs.
+
+Tolerances are for float32 arithmetic with different summation orders:
+rtol 2e-5 relative to the largest magnitude of the expected tensor, unless a
+test states otherwise.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle.ops_cpu import CpuOps, EPI_LEAKY, EPI_MUL, EPI_NONE, ATTN_NPARAM  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from cycle_gan_rna_amd.ops import HipOps
+    return HipOps("cuda:0")
+
+
+cpu = CpuOps()
+
+
+def close(got, exp, rtol=2e-5, what=""):
+    got = got.detach().cpu().double()
+    exp = exp.detach().double()
+    scale = max(float(exp.abs().max()), 1e-30)
+    err = float((got - exp).abs().max()) / scale
+    assert err <= rtol, f"{what}: rel err {err:.3e} > {rtol}"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return torch.randn(*shape, generator=g) * scale
+
+
+def dev(t):
+    return t.cuda() if t is not None else None
+
+
+GEMM_SHAPES = [
+    # M, N, K, transA, transB
+    (64, 64, 32, 0, 1), (128, 128, 64, 0, 1), (33, 70, 45, 0, 1), (512, 2048, 300, 0, 1), (512, 1024, 5012, 0, 1),
+    (100, 5000, 512, 0, 1), (8, 1, 256, 0, 1), (257, 129, 31, 0, 0), (512, 268, 2048, 0, 0), (64, 200, 1, 0, 0),
+    (1024, 212, 32, 1, 0), (96, 48, 515, 1, 0), (1, 256, 37, 1, 0), (16, 16, 8192, 1, 0), (70, 33, 19, 1, 1),
+    (1536, 1024, 512, 0, 1),
+]
+
+
+@pytest.mark.parametrize("M,N,K,ta,tb", GEMM_SHAPES)
+def test_gemm_plain(ops, M, N, K, ta, tb):
+    A = rnd(*((K, M) if ta else (M, K)), seed=1)
+    B = rnd(*((N, K) if tb else (K, N)), seed=2)
+    bias = rnd(N, seed=3)
+    exp = torch.empty(M, N)
+    cpu.gemm(exp, A.double(), B.double(), ta, tb, bias=bias.double())
+    got = torch.full((M, N), float("nan")).cuda()
+    ops.gemm(got, dev(A), dev(B), ta, tb, bias=dev(bias))
+    close(got, exp, 2e-5, "gemm")
+
+
+def test_gemm_is_exact_fp32_fma_chain(ops):
+    """Small-integer data: every product and sum is exact, so any slip in the k
+    coverage or in the lane -> (row, col) map shows as an integer difference.
+    B is asymmetric so a transposed write cannot hide."""
+    M, N, K = 96, 160, 77
+    A = torch.randint(-3, 4, (M, K), generator=torch.Generator().manual_seed(0)).float()
+    B = (torch.arange(N * K).reshape(N, K) % 7 - 3).float()
+    got = torch.zeros(M, N).cuda()
+    ops.gemm(got, dev(A), dev(B), False, True)
+    assert torch.equal(got.cpu(), A @ B.t())
+
+
+def test_gemm_strided_views_and_offsets(ops):
+    """Operands that are column slices of wider matrices (the critic's first
+    layer reads W1[:, :G] and W1[:, G:], lda != K) and an unaligned base."""
+    M, G, E, N = 40, 50, 12, 96
+    W = rnd(N, G + E, seed=5)
+    x = rnd(M, G, seed=6)
+    e = rnd(M, E, seed=7)
+    Wd = dev(W)
+    got = torch.zeros(M, N).cuda()
+    ops.gemm(got, dev(x), Wd[:, :G], False, True)
+    ops.gemm(got, dev(e), Wd[:, G:], False, True, accumulate=True)
+    close(got, torch.cat([x, e], 1).double() @ W.double().t(), 2e-5, "split-K-by-column gemm")
+    # wgrad into a column slice of a wider gradient matrix
+    dh = rnd(M, N, seed=8)
+    dW = torch.zeros(N, G + E).cuda()
+    ops.gemm(dW[:, :G], dev(dh), dev(x), True, False, accumulate=True)
+    ops.gemm(dW[:, G:], dev(dh), dev(e), True, False, accumulate=True)
+    close(dW, dh.double().t() @ torch.cat([x, e], 1).double(), 2e-5, "wgrad into slices")
+
+
+@pytest.mark.parametrize("epi", [EPI_LEAKY, EPI_MUL])
+def test_gemm_epilogues(ops, epi):
+    M, N, K = 130, 200, 96
+    A, B, bias = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3)
+    E = (torch.rand(M, N, generator=torch.Generator().manual_seed(4)) < 0.7).float() / 0.7
+    exp, aux = torch.empty(M, N, dtype=torch.float64), torch.empty(M, N, dtype=torch.float64)
+    cpu.gemm(exp, A.double(), B.double(), False, True, bias=bias.double(), epi=epi, E=E.double(), aux=aux, slope=0.2)
+    got, gaux = torch.zeros(M, N).cuda(), torch.zeros(M, N).cuda()
+    ops.gemm(got, dev(A), dev(B), False, True, bias=dev(bias), epi=epi, E=dev(E), aux=gaux, slope=0.2)
+    close(got, exp, 2e-5, "epilogue C")
+    if epi == EPI_LEAKY:
+        # pm can legitimately flip where |h| is at rounding level; require agreement elsewhere
+        h = A.double() @ B.double().t() + bias.double()
+        ok = h.abs() > 1e-4
+        assert torch.equal(gaux.cpu().double()[ok], aux[ok])
+
+
+def test_gemm_rejects_bad_arguments(ops):
+    from cycle_gan_rna_amd._lib import CgError
+    a = torch.zeros(4, 8).cuda()
+    c = torch.zeros(4, 4).cuda()
+    with pytest.raises(AssertionError):
+        ops.gemm(c, a, torch.zeros(5, 9).cuda(), False, True)
+    with pytest.raises(CgError):
+        ops.gemm(c, a, torch.zeros(4, 8).cuda(), False, True, epi=EPI_MUL)   # E missing
+
+
+@pytest.mark.parametrize("M,N,slope,use_mask", [(512, 2048, 0.0, False), (37, 100, 0.2, True), (8192, 16, 1.0, False),
+                                                (2, 33, 0.0, False), (128, 1024, 0.2, True)])
+def test_bn_fwd_bwd(ops, M, N, slope, use_mask):
+    X = rnd(M, N, seed=1) * 2 + 0.7
+    gamma, beta = rnd(N, seed=2) + 1.5, rnd(N, seed=3)
+    mask = ((torch.rand(M, N, generator=torch.Generator().manual_seed(4)) < 0.7).float() / 0.7) if use_mask else None
+    rm, rv = rnd(N, seed=5), rnd(N, seed=6).abs() + 0.5
+    # expected (float64 inside CpuOps)
+    c64 = CpuOps(torch.float64)
+    d = lambda t: None if t is None else t.double()  # noqa: E731
+    eY, epm = torch.empty(M, N, dtype=torch.float64), torch.empty(M, N, dtype=torch.float64)
+    emean, einv = torch.empty(N, dtype=torch.float64), torch.empty(N, dtype=torch.float64)
+    erm, erv = rm.double().clone(), rv.double().clone()
+    c64.bn_fwd(eY, d(X), d(gamma), d(beta), emean, einv, erm, erv, slope, d(mask), epm)
+    gY, gpm = torch.empty(M, N).cuda(), torch.empty(M, N).cuda()
+    gmean, ginv, grm, grv = torch.empty(N).cuda(), torch.empty(N).cuda(), dev(rm.clone()), dev(rv.clone())
+    Xd = dev(X)
+    ops.bn_fwd(gY, Xd, dev(gamma), dev(beta), gmean, ginv, grm, grv, slope, dev(mask), gpm)
+    for g, e, w in [(gY, eY, "Y"), (gmean, emean, "mean"), (ginv, einv, "invstd"), (grm, erm, "rmean"), (grv, erv, "rvar")]:
+        close(g, e, 3e-5, f"bn_fwd {w}")
+    # backward, with and without parameter gradients / saved pm
+    dY = rnd(M, N, seed=7)
+    edX = torch.empty(M, N, dtype=torch.float64)
+    edg, edb = torch.ones(N, dtype=torch.float64), torch.ones(N, dtype=torch.float64)
+    egb, egx = torch.empty(N, dtype=torch.float64), torch.empty(N, dtype=torch.float64)
+    c64.bn_bwd(edX, d(dY), d(X), eY if not use_mask else None, epm if use_mask else None, emean, einv, d(gamma), edg, edb,
+               True, slope, egb, egx)
+    gdX, gdg, gdb = torch.empty(M, N).cuda(), torch.ones(N).cuda(), torch.ones(N).cuda()
+    ggb, ggx = torch.empty(N).cuda(), torch.empty(N).cuda()
+    ops.bn_bwd(gdX, dev(dY), Xd, gY if not use_mask else None, gpm if use_mask else None, gmean, ginv, dev(gamma), gdg,
+               gdb, True, slope, ggb, ggx)
+    for g, e, w in [(gdX, edX, "dX"), (gdg, edg, "dgamma"), (gdb, edb, "dbeta"), (ggb, egb, "gbar"), (ggx, egx, "gxbar")]:
+        close(g, e, 1e-4, f"bn_bwd {w}")
+
+
+def test_bn_bwd_matches_autograd():
+    """The CPU restatement of the BatchNorm backward itself against torch autograd (float64)."""
+    M, N = 24, 10
+    X = rnd(M, N, seed=1).double().requires_grad_(True)
+    gamma, beta = (rnd(N, seed=2) + 1.5).double().requires_grad_(True), rnd(N, seed=3).double().requires_grad_(True)
+    mu = X.mean(0)
+    var = ((X - mu) ** 2).mean(0)
+    h = (X - mu) / torch.sqrt(var + 1e-5) * gamma + beta
+    y = torch.where(h > 0, h, 0.2 * h)
+    dY = rnd(M, N, seed=4).double()
+    gx, gg, gb = torch.autograd.grad(y, (X, gamma, beta), dY)
+    c64 = CpuOps(torch.float64)
+    Y, pm, mean, inv = (torch.empty(M, N, dtype=torch.float64), torch.empty(M, N, dtype=torch.float64),
+                        torch.empty(N, dtype=torch.float64), torch.empty(N, dtype=torch.float64))
+    c64.bn_fwd(Y, X.detach(), gamma.detach(), beta.detach(), mean, inv, None, None, 0.2, None, pm)
+    dX, dg, db = torch.empty(M, N, dtype=torch.float64), torch.empty(N, dtype=torch.float64), torch.empty(N, dtype=torch.float64)
+    c64.bn_bwd(dX, dY, X.detach(), None, pm, mean, inv, gamma.detach(), dg, db, False, 0.2)
+    close(dX, gx, 1e-10), close(dg, gg, 1e-10), close(db, gb, 1e-10)
+
+
+def test_bn_bwd_bwd(ops):
+    M, N = 64, 100
+    X, W, U1 = rnd(M, N, seed=1) + 0.3, rnd(M, N, seed=2), rnd(M, N, seed=3)
+    gamma = rnd(N, seed=4) + 1.5
+    c64 = CpuOps(torch.float64)
+    mean, inv = torch.empty(N, dtype=torch.float64), torch.empty(N, dtype=torch.float64)
+    c64.bn_fwd(torch.empty(M, N, dtype=torch.float64), X.double(), gamma.double(), torch.zeros(N, dtype=torch.float64),
+               mean, inv, None, None, 1.0)
+    u0, ub, mb = torch.empty(M, N, dtype=torch.float64), torch.empty(N, dtype=torch.float64), torch.empty(N, dtype=torch.float64)
+    c64.bn_bwd(u0, U1.double(), X.double(), None, None, mean, inv, gamma.double(), None, None, False, 1.0, ub, mb)
+    eVu, eVh, edg = (torch.empty(M, N, dtype=torch.float64), torch.empty(M, N, dtype=torch.float64),
+                     torch.zeros(N, dtype=torch.float64))
+    c64.bn_bwd_bwd(eVu, eVh, edg, False, W.double(), U1.double(), X.double(), mean, inv, gamma.double(), ub, mb)
+    gVu, gVh, gdg = torch.empty(M, N).cuda(), torch.empty(M, N).cuda(), torch.zeros(N).cuda()
+    ops.bn_bwd_bwd(gVu, gVh, gdg, False, dev(W), dev(U1), dev(X), dev(mean.float()), dev(inv.float()), dev(gamma),
+                   dev(ub.float()), dev(mb.float()))
+    close(gVu, eVu, 1e-4, "V_u1"), close(gVh, eVh, 1e-4, "V_h0"), close(gdg, edg, 1e-4, "dgamma")
+
+
+def test_bn_bwd_bwd_matches_autograd():
+    """CPU restatement of the backward-of-backward against torch double autograd (float64)."""
+    M, N = 12, 7
+    X = (rnd(M, N, seed=1) + 0.3).double().requires_grad_(True)
+    gamma = (rnd(N, seed=4) + 1.5).double().requires_grad_(True)
+    U1 = rnd(M, N, seed=3).double().requires_grad_(True)
+    W = rnd(M, N, seed=2).double()
+    mu = X.mean(0)
+    inv = 1 / torch.sqrt(((X - mu) ** 2).mean(0) + 1e-5)
+    xh = (X - mu) * inv
+    u0 = inv * gamma * (U1 - U1.mean(0) - xh * (U1 * xh).mean(0))      # BatchNorm backward as a function
+    gX, gG, gU = torch.autograd.grad(u0, (X, gamma, U1), W)
+    c64 = CpuOps(torch.float64)
+    Vu, Vh, dg = (torch.empty(M, N, dtype=torch.float64), torch.empty(M, N, dtype=torch.float64),
+                  torch.zeros(N, dtype=torch.float64))
+    c64.bn_bwd_bwd(Vu, Vh, dg, False, W, U1.detach(), X.detach(), mu.detach(), inv.detach(), gamma.detach(),
+                   U1.detach().mean(0), (U1.detach() * xh.detach()).mean(0))
+    close(Vu, gU, 1e-10, "V_u1"), close(Vh, gX, 1e-10, "V_h0"), close(dg, gG, 1e-10, "dgamma")
+
+
+def test_elementwise_and_gathers(ops):
+    M, N = 70, 333
+    x, y = rnd(M, N, seed=1), rnd(M, N, seed=2)
+    out = torch.empty(M, N).cuda()
+    ops.axpby(out, 0.5, dev(x), -2.0, dev(y))
+    close(out, 0.5 * x - 2 * y, 1e-6)
+    ops.mul(out, dev(x), dev(y))
+    close(out, x * y, 1e-6)
+    coef = torch.tensor([0.0, 3.0, -1.5]).cuda()
+    ops.fill_coef(out, coef, 2, 0.5)
+    assert torch.equal(out.cpu(), torch.full((M, N), -0.75))
+    table = rnd(12, 12, seed=3)
+    labels = torch.randint(0, 12, (M, 1), generator=torch.Generator().manual_seed(4))
+    wide = torch.zeros(M, 268).cuda()
+    ops.embed_gather(wide[:, 256:], dev(table), dev(labels))
+    assert torch.equal(wide[:, 256:].cpu(), table[labels[:, 0]])
+    dout = rnd(M, 12, seed=5)
+    dt = torch.ones(12, 12).cuda()
+    ops.embed_scatter(dt, dev(dout), dev(labels), True)
+    exp = torch.ones(12, 12, dtype=torch.float64)
+    exp.index_add_(0, labels[:, 0], dout.double())
+    close(dt, exp, 1e-5)
+
+
+def test_reparam_libsize_gp(ops):
+    M, L = 50, 256
+    ml, eps, dz = rnd(M, 2 * L, seed=1) * 0.5, rnd(M, L, seed=2), rnd(M, L, seed=3)
+    z, ez = torch.empty(M, L).cuda(), torch.empty(M, L)
+    ops.reparam_fwd(z, dev(ml), dev(eps))
+    cpu.reparam_fwd(ez, ml, eps)
+    close(z, ez, 1e-5)
+    coef = torch.tensor([0.1, 0.2, 0.3, 0.4, 2.5])
+    dml, edml = torch.empty(M, 2 * L).cuda(), torch.empty(M, 2 * L)
+    ops.reparam_bwd(dml, dev(dz), dev(ml), dev(eps), dev(coef), 4, 1.0)
+    cpu.reparam_bwd(edml, dz, ml, eps, coef, 4, 1.0)
+    close(dml, edml, 1e-5)
+    G = 501
+    X, dY = rnd(M, G, seed=4), rnd(M, G, seed=5)
+    Y, rs, eY, ers = torch.empty(M, G).cuda(), torch.empty(M).cuda(), torch.empty(M, G), torch.empty(M)
+    ops.libsize_fwd(Y, dev(X), rs, 1e4)
+    cpu.libsize_fwd(eY, X, ers, 1e4)
+    close(Y, eY, 1e-5), close(rs, ers, 1e-5)
+    dX, edX = torch.empty(M, G).cuda(), torch.empty(M, G)
+    ops.libsize_bwd(dX, dev(dY), dev(X), rs, 1e4)
+    cpu.libsize_bwd(edX, dY, X, ers, 1e4)
+    close(dX, edX, 1e-4)
+    real, fake, alpha = rnd(M, G, seed=6), rnd(M, G, seed=7), torch.rand(M, 1, generator=torch.Generator().manual_seed(8))
+    o, eo = torch.empty(M, G).cuda(), torch.empty(M, G)
+    ops.gp_interp(o, dev(real), dev(fake), dev(alpha))
+    cpu.gp_interp(eo, real, fake, alpha)
+    close(o, eo, 1e-6)
+    V, rp, eV, erp = torch.empty(M, G).cuda(), torch.empty(M).cuda(), torch.empty(M, G), torch.empty(M)
+    ux = rnd(M, G, seed=9) * 0.05
+    ops.gp_penalty(V, rp, dev(ux), 13.0)
+    cpu.gp_penalty(eV, erp, ux, 13.0)
+    close(V, eV, 2e-5), close(rp, erp, 2e-5)
+
+
+def test_reductions_and_loss_bookkeeping(ops):
+    M, N = 200, 777
+    A, B = rnd(M, N, seed=1), rnd(M, N, seed=2)
+    Cn = rnd(12, N, seed=3)
+    labels = torch.randint(0, 12, (M, 1), generator=torch.Generator().manual_seed(4))
+    ml = rnd(M, 512, seed=5) * 0.3
+    red = (torch.zeros(8, 1024).cuda(), torch.zeros(8, dtype=torch.int32).cuda())
+    ered = (torch.zeros(8, 1024, dtype=torch.float64), torch.zeros(8, dtype=torch.int32))
+    c64 = CpuOps(torch.float64)
+    ops.reduce_sum(red, 0, dev(A)), c64.reduce_sum(ered, 0, A.double())
+    ops.reduce_l1(red, 1, dev(A), dev(B)), c64.reduce_l1(ered, 1, A.double(), B.double())
+    ops.reduce_centroid_sq(red, 2, dev(A), dev(Cn), dev(labels)), c64.reduce_centroid_sq(ered, 2, A.double(), Cn.double(), labels)
+    ops.reduce_kl(red, 3, dev(ml)), c64.reduce_kl(ered, 3, ml.double())
+    ops.reduce_sqdiff(red, 4, dev(A[0]), dev(B[0])), c64.reduce_sqdiff(ered, 4, A[0].double(), B[0].double())
+    ops.reduce_sum(red, 5, dev(A[:, :1])), c64.reduce_sum(ered, 5, A[:, :1].double())
+    slots = torch.arange(6, dtype=torch.int32)
+    scales = torch.tensor([1.0, 0.5, 2.0, -0.5, 1.0, 1.0], dtype=torch.float64)
+    tot, etot = torch.zeros(6, dtype=torch.float64).cuda(), torch.zeros(6, dtype=torch.float64)
+    ops.sum_parts(tot, red, dev(slots), dev(scales))
+    c64.sum_parts(etot, ered, slots, scales)
+    assert int(red[1][0]) <= 1024
+    close(tot, etot, 1e-5, "sum_parts")     # float32 partial sums inside each block
+    # loss bookkeeping: two consecutive calls (moving averages carry over)
+    desc = dict(terms=[[(0, -1.0 / M), (5, -1.0 / M)], [(1, 1.0 / (M * N))], [(2, 1.0 / (M * N))], [(4, 0.5 / N)],
+                       [(3, -0.5 / (M * 512))]], ema_alpha=0.3)
+    desc["lambda"] = [1.0, 1.0, 0.2, 0.3, 0.1]
+    ema, eema = torch.zeros(5, dtype=torch.float64).cuda(), torch.zeros(5, dtype=torch.float64)
+    losses, elosses = torch.zeros(11, dtype=torch.float64).cuda(), torch.zeros(11, dtype=torch.float64)
+    coef, ecoef = torch.zeros(5).cuda(), torch.zeros(5)
+    for _ in range(2):
+        ops.gloss_finalize(ema, losses, coef, red, desc)
+        c64.gloss_finalize(eema, elosses, ecoef, ered, desc)
+    close(losses, elosses, 1e-5, "losses"), close(coef, ecoef, 1e-5, "coef"), close(ema, eema, 1e-5, "ema")
+    out, eout = torch.zeros(N).cuda(), torch.zeros(N, dtype=torch.float64)
+    ops.colsum(out, dev(A), 1.0 / M), c64.colsum(eout, A.double(), 1.0 / M)
+    close(out, eout, 1e-5, "colmean")
+    v, ev = torch.zeros(1).cuda(), torch.zeros(1, dtype=torch.float64)
+    ops.colvar_mean(v, torch.zeros(64, dtype=torch.float64).cuda(), dev(A)), c64.colvar_mean(ev, None, A.double())
+    close(v, ev, 1e-5, "colvar")
+    # gradients of the loss terms
+    cf = torch.tensor([0.0, 2.0, 3.0, 4.0])
+    for fn, args, eargs in [
+        ("l1_bwd", (dev(A), dev(B), dev(cf), 1, 0.25), (A, B, cf, 1, 0.25)),
+        ("centroid_bwd", (dev(A), dev(Cn), dev(labels), dev(cf), 2, 0.5), (A, Cn, labels, cf, 2, 0.5)),
+    ]:
+        g, e = torch.ones(M, N).cuda(), torch.ones(M, N)
+        getattr(ops, fn)(g, *args, accumulate=True)
+        getattr(cpu, fn)(e, *eargs, accumulate=True)
+        close(g, e, 1e-6, fn)
+    g, e = torch.zeros(M, 256).cuda(), torch.zeros(M, 256)
+    mf, mr = rnd(256, seed=8), rnd(256, seed=9)
+    ops.fm_bwd(g, dev(mf), dev(mr), dev(cf), 3, 0.1), cpu.fm_bwd(e, mf, mr, cf, 3, 0.1)
+    close(g, e, 1e-6, "fm_bwd")
+
+
+def test_adam_matches_torch_optimizer(ops):
+    """Five steps of the fused kernel against torch.optim.Adam(amsgrad=True) on CPU."""
+    n = 10007
+    p0 = rnd(n, seed=1)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=3e-4, betas=(0.5, 0.9), amsgrad=True)
+    p = dev(p0.clone())
+    m, v, vm = torch.zeros(n).cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+    lr_step = torch.zeros(2, dtype=torch.float64).cuda()
+    for t in range(1, 6):
+        g = rnd(n, seed=10 + t) * (10.0 ** (t - 3))
+        ref.grad = g.clone()
+        opt.step()
+        lr_step.copy_(torch.tensor([3e-4, float(t)], dtype=torch.float64))
+        ops.adam(p, dev(g), m, v, vm, lr_step, 0.5, 0.9, 1e-8)
+    close(p, ref.detach(), 1e-6, "adam p")
+
+
+@pytest.mark.parametrize("n_cells,train", [(1, True), (7, True), (512, True), (33, False)])
+def test_attention_layernorm(ops, n_cells, train):
+    heads = 4
+    X = rnd(n_cells * 16, 16, seed=1)
+    params = rnd(ATTN_NPARAM, seed=2) * 0.3
+    params[1088:1104] += 1.0
+    keep = ((torch.rand(n_cells * heads, 16, 16, generator=torch.Generator().manual_seed(3)) < 0.9).float() / 0.9) if train else None
+    c64 = CpuOps(torch.float64)
+    eY = torch.empty(n_cells * 16, 16, dtype=torch.float64)
+    c64.attn_fwd(eY, X.double(), None if keep is None else keep.double(), params.double(), heads)
+    Y = torch.empty(n_cells * 16, 16).cuda()
+    ops.attn_fwd(Y, dev(X), dev(keep), dev(params), heads)
+    close(Y, eY, 2e-5, "attn fwd")
+    dY = rnd(n_cells * 16, 16, seed=4)
+    edX, edp = torch.empty(n_cells * 16, 16, dtype=torch.float64), torch.ones(ATTN_NPARAM, dtype=torch.float64)
+    c64.attn_bwd(edX, edp, None, dY.double(), X.double(), None if keep is None else keep.double(), params.double(), heads, True)
+    dX, dp = torch.empty(n_cells * 16, 16).cuda(), torch.ones(ATTN_NPARAM).cuda()
+    ws = torch.empty(ops.attn_bwd_ws(n_cells)).cuda()
+    ops.attn_bwd(dX, dp, ws, dev(dY), dev(X), dev(keep), dev(params), heads, True)
+    close(dX, edX, 5e-5, "attn dX")
+    close(dp, edp, 5e-5, "attn dparams")
