@@ -1,0 +1,674 @@
+"""Explicit forward / backward / update of one CycleGAN training iteration.
+
+This is the host side of the hot path: the loop body of
+train_enhanced_cycle_gan (reference GAN_functions.py:298-419) written as a fixed
+sequence of kernel launches through `ops` (ops.py:HipOps), with hand-derived
+backward passes instead of an autograd tape:
+
+  * GenPass   - GeneExpressionGenerator.forward (:132-150) and its backward
+  * DiscPass  - GeneExpressionDiscriminator.forward (:178-191), its backward,
+                and the gradient penalty's first- and second-order chains
+                (compute_gradient_penalty :194-204 followed by .backward())
+  * StepEngine.d_step / g_step - :322-340 and :343-419, including the loss
+                bookkeeping (:380-406, on the device) and Adam-amsgrad (:223-225)
+
+Two sweeps the reference's autograd performs and then throws away are not
+executed: the double backward from the penalty into the generators during the
+critic step (their grads are zeroed at :343 before use) and the critic parameter
+gradients during the generator step (zeroed at :322-323).  Losses, parameter
+updates and BatchNorm running statistics are unaffected.
+
+Parameters live in flat float32 arenas (one per optimizer) so that one fused
+Adam launch updates a whole optimizer; each named parameter is a view.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Dict, Optional
+
+import torch
+
+EPI_NONE, EPI_LEAKY, EPI_MUL = 0, 1, 2
+SEQ_LEN = 16
+BUFFER_SUFFIXES = ("running_mean", "running_var", "num_batches_tracked")
+
+# reduction slots
+(S_DM_REAL, S_DM_FAKE, S_DM_GP, S_DH_REAL, S_DH_FAKE, S_DH_GP,
+ S_ADV_H, S_ADV_M, S_CYC_M, S_CYC_H, S_CT_H, S_CT_M, S_FM_H, S_FM_M, S_KL_H, S_KL_M, N_SLOTS) = range(17)
+MAX_PARTS = 1024
+
+
+def _pad4(n):
+    return (n + 3) // 4 * 4
+
+
+class Arena:
+    """Flat float32 storage for the parameters of one optimizer (+ grads and
+    Adam state), with named views.  Every tensor starts on a 16-byte boundary;
+    the padding stays zero (zero gradient keeps Adam's update at zero)."""
+
+    def __init__(self, ops, named_shapes):
+        self.ops = ops
+        self.offsets = OrderedDict()
+        off = 0
+        for key, shape in named_shapes:
+            n = int(math.prod(shape)) if len(shape) else 1
+            self.offsets[key] = (off, n, tuple(shape))
+            off += _pad4(n)
+        self.n = off
+        self.p = ops.zeros(off)
+        self.g = ops.zeros(off)
+        self.m = ops.zeros(off)
+        self.v = ops.zeros(off)
+        self.vmax = ops.zeros(off)
+        self.lr_step = ops.zeros(2, dtype=torch.float64)
+        self.step = 0
+
+    def view(self, buf, key):
+        off, n, shape = self.offsets[key]
+        return buf[off:off + n].view(shape)
+
+    def flat(self, buf, key_first, n):
+        off = self.offsets[key_first][0]
+        return buf[off:off + n]
+
+
+def split_state(sd):
+    params = OrderedDict((k, v) for k, v in sd.items() if not k.endswith(BUFFER_SUFFIXES))
+    buffers = OrderedDict((k, v) for k, v in sd.items() if k.endswith(BUFFER_SUFFIXES))
+    return params, buffers
+
+
+def _arena_order(keys):
+    """state_dict order, with the (never used) sparse-attention gate moved to the
+    end so that each attention block's six tensors stay contiguous."""
+    gate = [k for k in keys if ".gate." in k]
+    return [k for k in keys if ".gate." not in k] + gate
+
+
+class Net:
+    """Device-side parameters (arena views), gradients and buffers of one network."""
+
+    def __init__(self, name, arena, keys, buffers, ops):
+        self.name = name
+        self.P = OrderedDict((k, arena.view(arena.p, (name, k))) for k in keys)
+        self.G = OrderedDict((k, arena.view(arena.g, (name, k))) for k in keys)
+        self.B = OrderedDict()
+        self.nbt = OrderedDict()
+        for k, v in buffers.items():
+            if k.endswith("num_batches_tracked"):
+                self.nbt[k] = int(v)
+            else:
+                self.B[k] = ops.to_device(v.detach().clone().float())
+        self.arena = arena
+
+    def state_dict(self):
+        sd = OrderedDict()
+        for k, v in self.P.items():
+            sd[k] = v.detach().cpu().clone()
+        for k, v in self.B.items():
+            sd[k] = v.detach().cpu().clone()
+        for k, v in self.nbt.items():
+            sd[k] = torch.tensor(v, dtype=torch.long)
+        return sd
+
+    def load(self, sd):
+        for k, v in sd.items():
+            if k in self.P:
+                self.P[k].copy_(v.reshape(self.P[k].shape))
+            elif k in self.B:
+                self.B[k].copy_(v)
+            elif k in self.nbt:
+                self.nbt[k] = int(v)
+
+
+# --------------------------------------------------------------------------- #
+class GenPass:
+    """Workspace + forward/backward of one call of a generator on a batch."""
+
+    def __init__(self, engine, net: Net, in_dim, out_dim, max_b):
+        ops, cfg = engine.ops, engine.cfg
+        self.e, self.ops, self.net, self.cfg = engine, ops, net, cfg
+        self.in_dim, self.out_dim = in_dim, out_dim
+        self.hidden = list(cfg["hidden_dims"])
+        self.L = cfg["latent_dim"]
+        self.nb = cfg["residual_blocks"]
+        self.heads = cfg["num_attention_heads"]
+        self.E = engine.emb_dim
+        self.counts = cfg.get("preprocess_type", "counts") == "counts"
+        assert self.L // SEQ_LEN == 16 and self.heads == 4, \
+            "the fused attention kernel is built for latent_dim=256 (16 tokens x 16) and 4 heads"
+        Z, B, H, L = ops.zeros, max_b, self.hidden, self.L
+        T = B * SEQ_LEN
+        self.enc_h0 = [Z(B, h) for h in H]
+        self.enc_a = [Z(B, h) for h in H]
+        self.enc_stats = [(Z(h), Z(h)) for h in H]
+        self.ml = Z(B, 2 * L)
+        self.z = [Z(B, L) for _ in range(self.nb + 1)]
+        self.t1 = [Z(T, 16) for _ in range(self.nb)]
+        self.r = [Z(T, 16) for _ in range(self.nb)]
+        self.t2 = [Z(T, 16) for _ in range(self.nb)]
+        self.y = [Z(T, 16) for _ in range(self.nb)]
+        self.u = Z(T, 16)
+        self.rb_stats = [((Z(16), Z(16)), (Z(16), Z(16))) for _ in range(self.nb)]
+        self.keep = [None] * self.nb
+        self.dec_in = Z(B, L + self.E)
+        self.dec_h0 = [Z(B, h) for h in H]
+        self.dec_a = [Z(B, h) for h in H]
+        self.dec_stats = [(Z(h), Z(h)) for h in H]
+        self.out_raw = Z(B, out_dim)
+        self.out = Z(B, out_dim) if self.counts else self.out_raw
+        self.rowsum = Z(B)
+        # backward scratch
+        self.d_out_raw = Z(B, out_dim) if self.counts else None
+        self.d_act = [Z(B, h) for h in H]
+        self.d_h0 = [Z(B, h) for h in H]
+        self.d_dec_in = Z(B, L + self.E)
+        self.dz = [Z(B, L), Z(B, L)]
+        self.d16 = [Z(T, 16), Z(T, 16)]
+        self.dml = Z(B, 2 * L)
+        self.attn_ws = Z(max(ops.attn_bwd_ws(B), 1))
+        self.eps = None
+        self.labels = None
+        self.x = None
+        self.b = 0
+
+    # attention parameter block of residual block `bi` (params or grads)
+    def _attn(self, which, bi):
+        first = f"residual_attention_blocks.{bi}.1.attention.in_proj_weight"
+        return self.net.arena.flat(getattr(self.net.arena, which), (self.net.name, first), 1120)
+
+    def _bn(self, prefix):
+        P, Bf = self.net.P, self.net.B
+        return (P[prefix + ".weight"], P[prefix + ".bias"], Bf[prefix + ".running_mean"], Bf[prefix + ".running_var"])
+
+    def _linear_bn_relu(self, out_a, out_h0, stats, a, lin, bn, train):
+        ops, P = self.ops, self.net.P
+        ops.gemm(out_h0, a, P[lin + ".weight"], False, True, bias=P[lin + ".bias"])
+        gamma, beta, rm, rv = self._bn(bn)
+        if train:
+            ops.bn_fwd(out_a, out_h0, gamma, beta, stats[0], stats[1], rm, rv, 0.0)
+            self.net.nbt[bn + ".num_batches_tracked"] += 1
+        else:
+            ops.bn_eval(out_a, out_h0, gamma, beta, rm, rv, 0.0)
+
+    def forward(self, x, labels, noise, train=True):
+        ops, P, L = self.ops, self.net.P, self.L
+        b = x.shape[0]
+        self.b, self.x, self.labels, self.train = b, x, labels, train
+        nh = len(self.hidden)
+        a = x
+        for li in range(nh):
+            self._linear_bn_relu(self.enc_a[li][:b], self.enc_h0[li][:b], self.enc_stats[li], a,
+                                 f"encoder.{3 * li}", f"encoder.{3 * li + 1}", train)
+            a = self.enc_a[li][:b]
+        ml = self.ml[:b]
+        ops.gemm(ml[:, :L], a, P["mu.weight"], False, True, bias=P["mu.bias"])
+        ops.gemm(ml[:, L:], a, P["log_var.weight"], False, True, bias=P["log_var.bias"])
+        self.eps = noise.randn((b, L))
+        ops.reparam_fwd(self.z[0][:b], ml, self.eps)
+        t = b * SEQ_LEN
+        for bi in range(self.nb):
+            pre = f"residual_attention_blocks.{bi}"
+            zin = self.z[bi][:b].view(t, 16)
+            t1, r, t2, y, u = self.t1[bi][:t], self.r[bi][:t], self.t2[bi][:t], self.y[bi][:t], self.u[:t]
+            (s1, s2) = self.rb_stats[bi]
+            ops.gemm(t1, zin, P[pre + ".0.block.0.weight"], False, True, bias=P[pre + ".0.block.0.bias"])
+            g1, b1, rm1, rv1 = self._bn(pre + ".0.block.1")
+            g2, b2, rm2, rv2 = self._bn(pre + ".0.block.4")
+            if train:
+                ops.bn_fwd(r, t1, g1, b1, s1[0], s1[1], rm1, rv1, 0.0)
+                self.net.nbt[pre + ".0.block.1.num_batches_tracked"] += 1
+            else:
+                ops.bn_eval(r, t1, g1, b1, rm1, rv1, 0.0)
+            ops.gemm(t2, r, P[pre + ".0.block.3.weight"], False, True, bias=P[pre + ".0.block.3.bias"])
+            if train:
+                ops.bn_fwd(u, t2, g2, b2, s2[0], s2[1], rm2, rv2, 1.0)
+                self.net.nbt[pre + ".0.block.4.num_batches_tracked"] += 1
+            else:
+                ops.bn_eval(u, t2, g2, b2, rm2, rv2, 1.0)
+            ops.axpby(y, 1.0, zin, 1.0, u)
+            self.keep[bi] = noise.keep((b * self.heads, SEQ_LEN, SEQ_LEN), 0.1) if train else None
+            ops.attn_fwd(self.z[bi + 1][:b].view(t, 16), y, self.keep[bi], self._attn("p", bi), self.heads)
+        dec_in = self.dec_in[:b]
+        ops.axpby(dec_in[:, :L], 1.0, self.z[self.nb][:b])
+        if labels is not None:
+            ops.embed_gather(dec_in[:, L:], P["embeddings.0.weight"], labels)
+        else:
+            dec_in[:, L:].zero_()
+        a = dec_in
+        for li in range(nh):
+            self._linear_bn_relu(self.dec_a[li][:b], self.dec_h0[li][:b], self.dec_stats[li], a,
+                                 f"decoder.{3 * li}", f"decoder.{3 * li + 1}", train)
+            a = self.dec_a[li][:b]
+        last = f"decoder.{3 * nh}"
+        ops.gemm(self.out_raw[:b], a, P[last + ".weight"], False, True, bias=P[last + ".bias"])
+        if self.counts:
+            ops.libsize_fwd(self.out[:b], self.out_raw[:b], self.rowsum[:b], self.cfg["library_size"])
+        return self.out[:b]
+
+    def mu(self):
+        return self.ml[:self.b, :self.L]
+
+    def log_var(self):
+        return self.ml[:self.b, self.L:]
+
+    def _bn_linear_bwd(self, d_act, d_h0, h0, act, stats, a_prev, lin, bn, d_prev):
+        """Backward of Linear -> BatchNorm -> ReLU; d_prev (may be None) receives the input gradient."""
+        ops, P, G = self.ops, self.net.P, self.net.G
+        ops.bn_bwd(d_h0, d_act, h0, act, None, stats[0], stats[1], P[bn + ".weight"], G[bn + ".weight"],
+                   G[bn + ".bias"], True, 0.0)
+        ops.gemm(G[lin + ".weight"], d_h0, a_prev, True, False, accumulate=True)
+        # the Linear bias feeds a BatchNorm: its gradient is identically zero and is left at zero
+        if d_prev is not None:
+            ops.gemm(d_prev, d_h0, P[lin + ".weight"], False, False)
+
+    def backward(self, d_out, need_dx=False, dx_out=None, dx_accumulate=False, kl=None, d_mu=None, d_lv=None):
+        """d_out: gradient w.r.t. the returned output.  kl = (coef, idx, weight)
+        adds the KL term's gradient; d_mu / d_lv add gradients arriving at the
+        returned mu / log_var.  Parameter gradients are accumulated into the
+        arena; returns dx (gradient w.r.t. the input) when need_dx."""
+        ops, P, G, L, b = self.ops, self.net.P, self.net.G, self.L, self.b
+        nh = len(self.hidden)
+        t = b * SEQ_LEN
+        d = d_out
+        if self.counts:
+            ops.libsize_bwd(self.d_out_raw[:b], d_out, self.out_raw[:b], self.rowsum[:b], self.cfg["library_size"])
+            d = self.d_out_raw[:b]
+        last = f"decoder.{3 * nh}"
+        ops.gemm(G[last + ".weight"], d, self.dec_a[nh - 1][:b], True, False, accumulate=True)
+        ops.colsum(G[last + ".bias"], d, 1.0, True)
+        ops.gemm(self.d_act[nh - 1][:b], d, P[last + ".weight"], False, False)
+        for li in reversed(range(nh)):
+            a_prev = self.dec_a[li - 1][:b] if li > 0 else self.dec_in[:b]
+            d_prev = self.d_act[li - 1][:b] if li > 0 else self.d_dec_in[:b]
+            self._bn_linear_bwd(self.d_act[li][:b], self.d_h0[li][:b], self.dec_h0[li][:b], self.dec_a[li][:b],
+                                self.dec_stats[li], a_prev, f"decoder.{3 * li}", f"decoder.{3 * li + 1}", d_prev)
+        ddi = self.d_dec_in[:b]
+        if self.labels is not None:
+            ops.embed_scatter(G["embeddings.0.weight"], ddi[:, L:], self.labels, True)
+        cur = 0
+        ops.axpby(self.dz[cur][:b], 1.0, ddi[:, :L])
+        dz = self.dz[cur][:b].view(t, 16)
+        for bi in reversed(range(self.nb)):
+            pre = f"residual_attention_blocks.{bi}"
+            (s1, s2) = self.rb_stats[bi]
+            dy = self.dz[1 - cur][:b].view(t, 16)
+            ops.attn_bwd(dy, self._attn("g", bi), self.attn_ws, dz, self.y[bi][:t], self.keep[bi], self._attn("p", bi),
+                         self.heads, True)
+            dt2, dr = self.d16[0][:t], self.d16[1][:t]
+            ops.bn_bwd(dt2, dy, self.t2[bi][:t], None, None, s2[0], s2[1], P[pre + ".0.block.4.weight"],
+                       G[pre + ".0.block.4.weight"], G[pre + ".0.block.4.bias"], True, 1.0)
+            ops.gemm(G[pre + ".0.block.3.weight"], dt2, self.r[bi][:t], True, False, accumulate=True)
+            ops.gemm(dr, dt2, P[pre + ".0.block.3.weight"], False, False)
+            dt1 = dt2
+            ops.bn_bwd(dt1, dr, self.t1[bi][:t], self.r[bi][:t], None, s1[0], s1[1], P[pre + ".0.block.1.weight"],
+                       G[pre + ".0.block.1.weight"], G[pre + ".0.block.1.bias"], True, 0.0)
+            zin = self.z[bi][:b].view(t, 16)
+            ops.gemm(G[pre + ".0.block.0.weight"], dt1, zin, True, False, accumulate=True)
+            ops.gemm(dy, dt1, P[pre + ".0.block.0.weight"], False, False, accumulate=True)   # dzin = dy + dt1 L0
+            cur = 1 - cur
+            dz = dy
+        dz0 = self.dz[cur][:b]
+        dml = self.dml[:b]
+        coef, idx, w = kl if kl is not None else (None, 0, 0.0)
+        ops.reparam_bwd(dml, dz0, self.ml[:b], self.eps, coef, idx, w)
+        if d_mu is not None:
+            ops.axpby(dml[:, :L], 1.0, dml[:, :L], 1.0, d_mu)
+        if d_lv is not None:
+            ops.axpby(dml[:, L:], 1.0, dml[:, L:], 1.0, d_lv)
+        a_enc = self.enc_a[nh - 1][:b]
+        ops.gemm(G["mu.weight"], dml[:, :L], a_enc, True, False, accumulate=True)
+        ops.colsum(G["mu.bias"], dml[:, :L], 1.0, True)
+        ops.gemm(G["log_var.weight"], dml[:, L:], a_enc, True, False, accumulate=True)
+        ops.colsum(G["log_var.bias"], dml[:, L:], 1.0, True)
+        da = self.d_act[nh - 1][:b]
+        ops.gemm(da, dml[:, :L], P["mu.weight"], False, False)
+        ops.gemm(da, dml[:, L:], P["log_var.weight"], False, False, accumulate=True)
+        dx = None
+        for li in reversed(range(nh)):
+            a_prev = self.enc_a[li - 1][:b] if li > 0 else self.x
+            d_prev = self.d_act[li - 1][:b] if li > 0 else None
+            self._bn_linear_bwd(self.d_act[li][:b], self.d_h0[li][:b], self.enc_h0[li][:b], self.enc_a[li][:b],
+                                self.enc_stats[li], a_prev, f"encoder.{3 * li}", f"encoder.{3 * li + 1}", d_prev)
+        if need_dx:
+            dx = dx_out if dx_out is not None else ops.zeros(b, self.in_dim)
+            ops.gemm(dx, self.d_h0[0][:b], P["encoder.0.weight"], False, False, accumulate=dx_accumulate)
+        return dx
+
+
+# --------------------------------------------------------------------------- #
+class DiscPass:
+    """Workspace + forward/backward of one call of a critic on a batch."""
+
+    def __init__(self, engine, net: Net, in_dim, max_b):
+        ops = engine.ops
+        self.e, self.ops, self.net = engine, ops, net
+        self.Gd, self.E = in_dim, engine.emb_dim
+        Z, B = ops.zeros, max_b
+        self.emb = Z(B, self.E)
+        self.h0, self.a1, self.pm1 = Z(B, 1024), Z(B, 1024), Z(B, 1024)
+        self.stats = (Z(1024), Z(1024))
+        self.a2, self.pm2 = Z(B, 512), Z(B, 512)
+        self.a3, self.pm3 = Z(B, 256), Z(B, 256)
+        self.val = Z(B, 1)
+        # backward scratch
+        self.dval = Z(B, 1)
+        self.ones = ops.to_device(torch.ones(B, 1))
+        self.g256, self.g512, self.g1024a, self.g1024b = Z(B, 256), Z(B, 512), Z(B, 1024), Z(B, 1024)
+        self.h256, self.h512, self.h1024a, self.h1024b = Z(B, 256), Z(B, 512), Z(B, 1024), Z(B, 1024)
+        self.demb = Z(B, self.E)
+        self.ux = Z(B, in_dim)
+        self.rowpen = Z(B)
+        self.ubar, self.mbar = Z(1024), Z(1024)
+        self.x = None
+        self.labels = None
+        self.b = 0
+
+    def forward(self, x, labels, noise, train=True):
+        ops, P, Bf, Gd = self.ops, self.net.P, self.net.B, self.Gd
+        b = x.shape[0]
+        self.b, self.x, self.labels = b, x, labels
+        W1 = P["model.0.weight"]
+        emb = self.emb[:b]
+        if labels is not None:
+            ops.embed_gather(emb, P["embeddings.0.weight"], labels)
+        else:
+            emb.zero_()
+        h0 = self.h0[:b]
+        ops.gemm(h0, x, W1[:, :Gd], False, True, bias=P["model.0.bias"])
+        ops.gemm(h0, emb, W1[:, Gd:], False, True, accumulate=True)
+        if train:
+            m1 = noise.keep((b, 1024), 0.3)
+            ops.bn_fwd(self.a1[:b], h0, P["model.1.weight"], P["model.1.bias"], self.stats[0], self.stats[1],
+                       Bf["model.1.running_mean"], Bf["model.1.running_var"], 0.2, m1, self.pm1[:b])
+            self.net.nbt["model.1.num_batches_tracked"] += 1
+            m2 = noise.keep((b, 512), 0.3)
+        else:
+            ops.bn_eval(self.a1[:b], h0, P["model.1.weight"], P["model.1.bias"], Bf["model.1.running_mean"],
+                        Bf["model.1.running_var"], 0.2)
+            m2 = None
+        ops.gemm(self.a2[:b], self.a1[:b], P["model.4.weight"], False, True, bias=P["model.4.bias"], epi=EPI_LEAKY,
+                 E=m2, aux=self.pm2[:b], slope=0.2)
+        ops.gemm(self.a3[:b], self.a2[:b], P["model.7.weight"], False, True, bias=P["model.7.bias"], epi=EPI_LEAKY,
+                 E=None, aux=self.pm3[:b], slope=0.2)
+        ops.gemm(self.val[:b], self.a3[:b], P["model.9.weight"], False, True, bias=P["model.9.bias"])
+        return self.val[:b], self.a3[:b]
+
+    def backward(self, coef=None, idx=0, scale=0.0, dfeat=None, param_grads=True, dx_out=None):
+        """Gradient of  coef[idx]*scale*sum(validity) + <dfeat, features>.
+        param_grads: accumulate into the critic's gradient arena (critic step);
+        dx_out: accumulate the input gradient there (generator step)."""
+        ops, P, G, Gd, b = self.ops, self.net.P, self.net.G, self.Gd, self.b
+        W1 = P["model.0.weight"]
+        dh3 = self.g256[:b]
+        if coef is not None:
+            dval = self.dval[:b]
+            ops.fill_coef(dval, coef, idx, scale)
+            if param_grads:
+                ops.gemm(G["model.9.weight"], dval, self.a3[:b], True, False, accumulate=True)
+                ops.colsum(G["model.9.bias"], dval, 1.0, True)
+            ops.gemm(dh3, dval, P["model.9.weight"], False, False, epi=EPI_MUL, E=self.pm3[:b])
+            if dfeat is not None:
+                tmp = self.h256[:b]
+                ops.mul(tmp, dfeat, self.pm3[:b])
+                ops.axpby(dh3, 1.0, dh3, 1.0, tmp)
+        else:
+            ops.mul(dh3, dfeat, self.pm3[:b])
+        if param_grads:
+            ops.gemm(G["model.7.weight"], dh3, self.a2[:b], True, False, accumulate=True)
+            ops.colsum(G["model.7.bias"], dh3, 1.0, True)
+        dh2 = self.g512[:b]
+        ops.gemm(dh2, dh3, P["model.7.weight"], False, False, epi=EPI_MUL, E=self.pm2[:b])
+        if param_grads:
+            ops.gemm(G["model.4.weight"], dh2, self.a1[:b], True, False, accumulate=True)
+            ops.colsum(G["model.4.bias"], dh2, 1.0, True)
+        da1 = self.g1024a[:b]
+        ops.gemm(da1, dh2, P["model.4.weight"], False, False)
+        dh0 = self.g1024b[:b]
+        ops.bn_bwd(dh0, da1, self.h0[:b], None, self.pm1[:b], self.stats[0], self.stats[1], P["model.1.weight"],
+                   G["model.1.weight"] if param_grads else None, G["model.1.bias"] if param_grads else None, True, 0.2)
+        if param_grads:
+            gW1 = G["model.0.weight"]
+            ops.gemm(gW1[:, :Gd], dh0, self.x, True, False, accumulate=True)
+            ops.gemm(gW1[:, Gd:], dh0, self.emb[:b], True, False, accumulate=True)
+            if self.labels is not None:
+                ops.gemm(self.demb[:b], dh0, W1[:, Gd:], False, False)
+                ops.embed_scatter(G["embeddings.0.weight"], self.demb[:b], self.labels, True)
+        if dx_out is not None:
+            ops.gemm(dx_out, dh0, W1[:, :Gd], False, False, accumulate=True)
+
+    def gp_backward(self, lambda_gp, red, slot):
+        """After forward(interpolates, labels): the first-order chain to the input
+        gradient, the penalty (row terms reduced into `slot`), and the
+        second-order chain accumulating d(lambda*penalty)/d(params)."""
+        ops, P, G, Gd, b = self.ops, self.net.P, self.net.G, self.Gd, self.b
+        W1, W2, W3, w4 = P["model.0.weight"], P["model.4.weight"], P["model.7.weight"], P["model.9.weight"]
+        u3, u2, u1, u0 = self.g256[:b], self.g512[:b], self.g1024a[:b], self.g1024b[:b]
+        ops.gemm(u3, self.ones[:b], w4, False, False, epi=EPI_MUL, E=self.pm3[:b])
+        ops.gemm(u2, u3, W3, False, False, epi=EPI_MUL, E=self.pm2[:b])
+        ops.gemm(u1, u2, W2, False, False, epi=EPI_MUL, E=self.pm1[:b])
+        ops.bn_bwd(u0, u1, self.h0[:b], None, None, self.stats[0], self.stats[1], P["model.1.weight"], None, None,
+                   False, 1.0, self.ubar, self.mbar)
+        ux = self.ux[:b]
+        ops.gemm(ux, u0, W1[:, :Gd], False, False)
+        ops.gp_penalty(ux, self.rowpen[:b], ux, lambda_gp)          # ux now holds V
+        ops.reduce_sum(red, slot, self.rowpen[:b])
+        gW1 = G["model.0.weight"]
+        ops.gemm(gW1[:, :Gd], u0, ux, True, False, accumulate=True)
+        w = self.h1024a[:b]
+        ops.gemm(w, ux, W1[:, :Gd], False, True)
+        vu1, vh0 = self.h1024b[:b], self.h1024a[:b]
+        ops.bn_bwd_bwd(vu1, vh0, G["model.1.weight"], True, w, u1, self.h0[:b], self.stats[0], self.stats[1],
+                       P["model.1.weight"], self.ubar, self.mbar)
+        t1 = vu1
+        ops.mul(t1, vu1, self.pm1[:b])
+        ops.gemm(G["model.4.weight"], u2, t1, True, False, accumulate=True)
+        t2 = self.h512[:b]
+        ops.gemm(t2, t1, W2, False, True, epi=EPI_MUL, E=self.pm2[:b])
+        ops.gemm(G["model.7.weight"], u3, t2, True, False, accumulate=True)
+        vu3 = self.h256[:b]
+        ops.gemm(vu3, t2, W3, False, True, epi=EPI_MUL, E=self.pm3[:b])
+        ops.colsum(G["model.9.weight"], vu3, 1.0, True)
+        ops.gemm(gW1[:, :Gd], vh0, self.x, True, False, accumulate=True)
+        ops.gemm(gW1[:, Gd:], vh0, self.emb[:b], True, False, accumulate=True)
+        if self.labels is not None:
+            ops.gemm(self.demb[:b], vh0, W1[:, Gd:], False, False)
+            ops.embed_scatter(G["embeddings.0.weight"], self.demb[:b], self.labels, True)
+
+
+# --------------------------------------------------------------------------- #
+class StepEngine:
+    """State of a training run on one device + the two halves of an iteration."""
+
+    def __init__(self, nets: Dict[str, Dict[str, torch.Tensor]], cfg: dict, mouse_centroids, human_centroids, ops,
+                 max_batch: int):
+        self.ops, self.cfg = ops, dict(cfg)
+        self.max_b = max_batch
+        gm = nets["g_m2h"]["encoder.0.weight"].shape[1]
+        gh = nets["g_h2m"]["encoder.0.weight"].shape[1]
+        self.g_mouse, self.g_human = gm, gh
+        self.emb_dim = nets["g_m2h"]["embeddings.0.weight"].shape[1]
+        assert not any(k.startswith("embeddings.1.") for k in nets["g_m2h"]), "one categorical covariate is supported"
+        split = {n: split_state(sd) for n, sd in nets.items()}
+        order = {n: _arena_order(list(split[n][0].keys())) for n in nets}
+        self.arena_g = Arena(ops, [((n, k), tuple(split[n][0][k].shape)) for n in ("g_m2h", "g_h2m") for k in order[n]])
+        self.arena_d = Arena(ops, [((n, k), tuple(split[n][0][k].shape)) for n in ("d_m", "d_h") for k in order[n]])
+        self.nets = {}
+        for n in ("g_m2h", "g_h2m", "d_m", "d_h"):
+            arena = self.arena_g if n.startswith("g_") else self.arena_d
+            net = Net(n, arena, order[n], split[n][1], ops)
+            for k in order[n]:
+                net.P[k].copy_(ops.to_device(split[n][0][k].detach().float()))
+            self.nets[n] = net
+        self.lr_g = cfg["lr"] * 1.5          # GAN_functions.py:223
+        self.lr_d = cfg["lr"]                # :224-225
+        self.mouse_centroids = ops.to_device(mouse_centroids.float()).contiguous()
+        self.human_centroids = ops.to_device(human_centroids.float()).contiguous()
+        B = max_batch
+        N = self.nets
+        self.gen_a = {"g_m2h": GenPass(self, N["g_m2h"], gm, gh, B), "g_h2m": GenPass(self, N["g_h2m"], gh, gm, B)}
+        self.gen_b = {"g_m2h": GenPass(self, N["g_m2h"], gm, gh, B), "g_h2m": GenPass(self, N["g_h2m"], gh, gm, B)}
+        self.disc = {
+            "d_m": [DiscPass(self, N["d_m"], gm, B) for _ in range(3)],
+            "d_h": [DiscPass(self, N["d_h"], gh, B) for _ in range(3)],
+        }
+        Z = ops.zeros
+        self.red = (Z(N_SLOTS, MAX_PARTS), Z(N_SLOTS, dtype=torch.int32))
+        self.xhat = {"d_m": Z(B, gm), "d_h": Z(B, gh)}
+        self.d_fake = {"human": Z(B, gh), "mouse": Z(B, gm)}
+        self.d_recov = {"mouse": Z(B, gm), "human": Z(B, gh)}
+        self.fm_mean = {k: Z(256) for k in ("h_real", "h_fake", "m_real", "m_fake")}
+        self.d_feat = Z(B, 256)
+        self.one = ops.to_device(torch.ones(1))
+        self.ema = Z(5, dtype=torch.float64)                 # :283-287
+        self.gloss = Z(11, dtype=torch.float64)
+        self.coef = Z(5)
+        self.d_tot = Z(6, dtype=torch.float64)
+        self.d_slots = ops.to_device(torch.arange(6, dtype=torch.int32))
+        self.d_scales = Z(6, dtype=torch.float64)
+        self.var_out = Z(2)
+        self.var_ws = Z(max((max(gm, gh) + 31) // 32, 1), dtype=torch.float64)
+        self._d_scales_b = None
+
+    # ---- optimizer ---------------------------------------------------------------
+    def set_lr(self, lr):
+        """LRDecayScheduler writes one lr into all three optimizers (:244-246)."""
+        self.lr_g = lr
+        self.lr_d = lr
+
+    def _adam(self, arena, lr):
+        arena.step += 1
+        arena.lr_step.copy_(torch.tensor([lr, float(arena.step)], dtype=torch.float64))
+        self.ops.adam(arena.p, arena.g, arena.m, arena.v, arena.vmax, arena.lr_step, 0.5, 0.9, 1e-8)
+
+    # ---- critic step (:322-340) -------------------------------------------------------
+    def d_step(self, mouse, human, mouse_cat, human_cat, noise):
+        ops, cfg = self.ops, self.cfg
+        b = mouse.shape[0]
+        assert human.shape[0] == b and b <= self.max_b
+        self.arena_d.g.zero_()
+        fake_human = self.gen_a["g_m2h"].forward(mouse, mouse_cat, noise)
+        fake_mouse = self.gen_a["g_h2m"].forward(human, human_cat, noise)
+        plan = (("d_m", mouse, mouse_cat, fake_mouse, human_cat, S_DM_REAL),
+                ("d_h", human, human_cat, fake_human, mouse_cat, S_DH_REAL))
+        for name, real, real_lab, fake, fake_lab, s0 in plan:
+            dp = self.disc[name][0]
+            val, _ = dp.forward(real, real_lab, noise)
+            ops.reduce_sum(self.red, s0, val)
+            dp.backward(self.one, 0, -1.0 / b, param_grads=True)
+            val, _ = dp.forward(fake, fake_lab, noise)
+            ops.reduce_sum(self.red, s0 + 1, val)
+            dp.backward(self.one, 0, 1.0 / b, param_grads=True)
+            alpha = noise.rand((b, 1))
+            xhat = self.xhat[name][:b]
+            ops.gp_interp(xhat, real, fake, alpha)
+            dp.forward(xhat, fake_lab, noise)
+            dp.gp_backward(cfg["lambda_gp"], self.red, s0 + 2)
+        self._adam(self.arena_d, self.lr_d)
+        if self._d_scales_b != b:
+            lam = float(cfg["lambda_gp"])
+            self.d_scales.copy_(torch.tensor([-1.0 / b, 1.0 / b, lam / b] * 2, dtype=torch.float64))
+            self._d_scales_b = b
+        ops.sum_parts(self.d_tot, self.red, self.d_slots, self.d_scales)
+
+    def d_losses(self):
+        t = self.d_tot.cpu()
+        f32 = lambda v: float(torch.tensor(v, dtype=torch.float32))  # noqa: E731
+        return dict(d_m_loss=f32(float(t[0]) + float(t[1]) + float(t[2])),
+                    d_h_loss=f32(float(t[3]) + float(t[4]) + float(t[5])),
+                    gp_m=float(t[2]) / float(self.cfg["lambda_gp"]), gp_h=float(t[5]) / float(self.cfg["lambda_gp"]))
+
+    # ---- generator step (:343-419) -------------------------------------------------------
+    def g_step(self, mouse, human, mouse_cat, human_cat, noise):
+        ops, cfg = self.ops, self.cfg
+        b = mouse.shape[0]
+        gm, gh = self.g_mouse, self.g_human
+        self.arena_g.g.zero_()
+        A, Bp = self.gen_a["g_m2h"], self.gen_a["g_h2m"]
+        fake_human = A.forward(mouse, mouse_cat, noise)
+        fake_mouse = Bp.forward(human, human_cat, noise)
+        dh_adv, dh_fm, dh_tmp = self.disc["d_h"]
+        dm_adv, dm_fm, dm_tmp = self.disc["d_m"]
+        val_h, _ = dh_adv.forward(fake_human, human_cat, noise)            # :347
+        val_m, _ = dm_adv.forward(fake_mouse, mouse_cat, noise)
+        Rm, Rh = self.gen_b["g_h2m"], self.gen_b["g_m2h"]
+        recov_mouse = Rm.forward(fake_human, human_cat, noise)             # :349-350
+        recov_human = Rh.forward(fake_mouse, mouse_cat, noise)
+        red = self.red
+        ops.reduce_sum(red, S_ADV_H, val_h)
+        ops.reduce_sum(red, S_ADV_M, val_m)
+        ops.reduce_l1(red, S_CYC_M, recov_mouse, mouse)                    # :353-357
+        ops.reduce_l1(red, S_CYC_H, recov_human, human)
+        ops.reduce_centroid_sq(red, S_CT_H, fake_human, self.human_centroids, mouse_cat)   # :363
+        ops.reduce_centroid_sq(red, S_CT_M, fake_mouse, self.mouse_centroids, human_cat)   # :364
+        _, f = dh_tmp.forward(human, human_cat, noise)                     # :366-368
+        ops.colsum(self.fm_mean["h_real"], f, 1.0 / b)
+        _, f = dh_fm.forward(fake_human, human_cat, noise)
+        ops.colsum(self.fm_mean["h_fake"], f, 1.0 / b)
+        ops.reduce_sqdiff(red, S_FM_H, self.fm_mean["h_real"], self.fm_mean["h_fake"])
+        _, f = dm_tmp.forward(mouse, mouse_cat, noise)                     # :370-372
+        ops.colsum(self.fm_mean["m_real"], f, 1.0 / b)
+        _, f = dm_fm.forward(fake_mouse, mouse_cat, noise)
+        ops.colsum(self.fm_mean["m_fake"], f, 1.0 / b)
+        ops.reduce_sqdiff(red, S_FM_M, self.fm_mean["m_real"], self.fm_mean["m_fake"])
+        ops.reduce_kl(red, S_KL_H, A.ml[:b])                               # :375-376
+        ops.reduce_kl(red, S_KL_M, Bp.ml[:b])
+        L = cfg["latent_dim"]
+        desc = dict(
+            terms=[[(S_ADV_H, -1.0 / b), (S_ADV_M, -1.0 / b)],
+                   [(S_CYC_M, 1.0 / (b * gm)), (S_CYC_H, 1.0 / (b * gh))],
+                   [(S_CT_H, 1.0 / (b * gh)), (S_CT_M, 1.0 / (b * gm))],
+                   [(S_FM_H, 0.5 / 256), (S_FM_M, 0.5 / 256)],
+                   [(S_KL_H, -0.5 / (b * L)), (S_KL_M, -0.5 / (b * L))]],
+            ema_alpha=0.3)
+        desc["lambda"] = [float(cfg["lambda_adv"]), float(cfg["lambda_cycle"]), float(cfg["lambda_celltype"]),
+                          float(cfg["lambda_fm"]), float(cfg["lambda_kl"])]
+        ops.gloss_finalize(self.ema, self.gloss, self.coef, red, desc)     # :380-406
+        coef = self.coef
+        # ---- backward: gradient w.r.t. fake_human / fake_mouse from the four loss terms ----
+        dfh, dfm = self.d_fake["human"][:b], self.d_fake["mouse"][:b]
+        ops.centroid_bwd(dfh, fake_human, self.human_centroids, mouse_cat, coef, 2, 2.0 / (b * gh))
+        ops.centroid_bwd(dfm, fake_mouse, self.mouse_centroids, human_cat, coef, 2, 2.0 / (b * gm))
+        dh_adv.backward(coef, 0, -1.0 / b, param_grads=False, dx_out=dfh)
+        dm_adv.backward(coef, 0, -1.0 / b, param_grads=False, dx_out=dfm)
+        dfe = self.d_feat[:b]
+        ops.fm_bwd(dfe, self.fm_mean["h_fake"], self.fm_mean["h_real"], coef, 3, 1.0 / (256 * b))
+        dh_fm.backward(None, dfeat=dfe, param_grads=False, dx_out=dfh)
+        ops.fm_bwd(dfe, self.fm_mean["m_fake"], self.fm_mean["m_real"], coef, 3, 1.0 / (256 * b))
+        dm_fm.backward(None, dfeat=dfe, param_grads=False, dx_out=dfm)
+        drm, drh = self.d_recov["mouse"][:b], self.d_recov["human"][:b]
+        ops.l1_bwd(drm, recov_mouse, mouse, coef, 1, 1.0 / (b * gm))
+        Rm.backward(drm, need_dx=True, dx_out=dfh, dx_accumulate=True)
+        ops.l1_bwd(drh, recov_human, human, coef, 1, 1.0 / (b * gh))
+        Rh.backward(drh, need_dx=True, dx_out=dfm, dx_accumulate=True)
+        A.backward(dfh, kl=(coef, 4, 1.0))
+        Bp.backward(dfm, kl=(coef, 4, 1.0))
+        self._adam(self.arena_g, self.lr_g)
+        ops.colvar_mean(self.var_out[0:1], self.var_ws, fake_human)        # :418-419
+        ops.colvar_mean(self.var_out[1:2], self.var_ws, fake_mouse)
+        self.fake_human, self.fake_mouse = fake_human, fake_mouse
+
+    def g_losses(self):
+        t = self.gloss.cpu()
+        v = self.var_out.cpu()
+        f32 = lambda x: float(torch.tensor(float(x), dtype=torch.float32))  # noqa: E731
+        return dict(g_adv=float(t[0]), cycle_loss=float(t[1]), celltype_loss=float(t[2]), fm_loss=float(t[3]),
+                    kl_loss=float(t[4]), g_loss=f32(t[5]),
+                    scales=dict(adv=float(t[6]), cycle=float(t[7]), celltype=float(t[8]), fm=float(t[9]), kl=float(t[10])),
+                    fake_human_var=float(v[0]), fake_mouse_var=float(v[1]))
+
+    def iteration(self, i, mouse, human, mouse_cat, human_cat, noise):
+        """One pass of the loop body :298-419; returns the metrics the reference
+        records (only on generator steps, like :411-419)."""
+        self.d_step(mouse, human, mouse_cat, human_cat, noise)
+        out = {}
+        if i % self.cfg["nb_critic"] == 0:
+            self.g_step(mouse, human, mouse_cat, human_cat, noise)
+            out.update(self.d_losses())
+            out.update(self.g_losses())
+        return out
+
+    def state_dict(self, name):
+        return self.nets[name].state_dict()

@@ -1,0 +1,102 @@
+"""Whole-step parity on the MI355X: the HIP engine against the CPU oracle (and,
+through it, the reference) on the same seeds, inputs and noise.
+
+Tolerances.  Both sides compute in float32 with different summation orders, and
+GAN training amplifies rounding differences from step to step: two CPU float32
+implementations of the same mathematics (the reference and the oracle) already
+differ by ~1e-6 after one iteration and ~1e-3 after a dozen (see
+tests/golden/trajectory_cfg1.pt: reference vs oracle).  The checks are therefore
+  - first iteration:     rel <= 1e-4 on every loss (the stated float32 target)
+  - later iterations:    rel <= 5e-3 over the first 6 iterations
+  - parameter updates:   relative L2 of (final - init) <= 2e-2, gauge
+                         parameters excluded (see oracle.is_gauge_param)
+"""
+import pytest
+import torch
+
+from oracle import cyclegan_oracle as O
+from tests.helpers import LOSS_KEYS, make_problem, rel, small_cfg, update_rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from cycle_gan_rna_amd.ops import HipOps
+    return HipOps("cuda:0")
+
+
+def run_both(ops, cfg, gm, gh, B, iters, seed=11):
+    from cycle_gan_rna_amd.engine import StepEngine
+    from cycle_gan_rna_amd.noise import HostReplayNoise
+    nets, xm, xh, lm, lh = make_problem(gm, gh, B, cfg)
+    lm2, lh2 = lm[:, None], lh[:, None]
+    cm, ch = O.centroid_table(xm, lm, 12), O.centroid_table(xh, lh, 12)
+    tr = O.OracleTrainer(nets, cfg, cm, ch)
+    torch.manual_seed(seed)
+    exp = [tr.iteration(i, xm, xh, lm2, lh2) for i in range(iters)]
+    eng = StepEngine(nets, cfg, cm, ch, ops, B)
+    noise = HostReplayNoise(ops.device)
+    dxm, dxh, dlm, dlh = xm.cuda(), xh.cuda(), lm2.cuda(), lh2.cuda()
+    torch.manual_seed(seed)
+    got = [eng.iteration(i, dxm, dxh, dlm, dlh, noise) for i in range(iters)]
+    torch.cuda.synchronize()
+    return nets, tr, eng, exp, got
+
+
+@pytest.mark.parametrize("ptype,gm,gh,B", [("log_normalized", 48, 40, 16), ("counts", 64, 64, 24),
+                                           ("log_normalized", 200, 200, 32)])
+def test_iterations_match_oracle(ops, ptype, gm, gh, B):
+    cfg = small_cfg(preprocess_type=ptype, nb_critic=2)
+    nets, tr, eng, exp, got = run_both(ops, cfg, gm, gh, B, iters=6)
+    for i, (e, g) in enumerate(zip(exp, got)):
+        if not g:
+            continue
+        tol = 1e-4 if i == 0 else 5e-3
+        for k in LOSS_KEYS:
+            assert rel(g[k], e[k]) <= tol, (i, k, g[k], e[k])
+    # generated expression of the last generator step
+    last = max(i for i, g in enumerate(got) if g)
+    assert rel(eng.fake_human, exp[last]["fake_human"]) <= 5e-3
+    assert rel(eng.fake_mouse, exp[last]["fake_mouse"]) <= 5e-3
+    # parameter updates
+    for n in ("g_m2h", "g_h2m", "d_m", "d_h"):
+        sd = eng.state_dict(n)
+        for k, v in sd.items():
+            if k.endswith("num_batches_tracked"):
+                assert int(v) == int(tr.nets[n][k]), (n, k)
+                continue
+            if O.is_gauge_param(k, sd):
+                continue
+            ref = tr.nets[n][k].detach()
+            if k.endswith(("running_mean", "running_var")):
+                assert rel(v, ref) <= 5e-3, (n, k)
+            else:
+                assert update_rel_l2(v, ref, nets[n][k]) <= 2e-2, (n, k, update_rel_l2(v, ref, nets[n][k]))
+
+
+def test_default_hidden_dims_one_iteration(ops):
+    """Default architecture (2048/1024/512 hidden) at a modest gene count."""
+    cfg = O.default_config(preprocess_type="log_normalized", nb_critic=1)
+    nets, tr, eng, exp, got = run_both(ops, cfg, 512, 512, 64, iters=2)
+    for k in LOSS_KEYS:
+        assert rel(got[0][k], exp[0][k]) <= 1e-4, (k, got[0][k], exp[0][k])
+        assert rel(got[1][k], exp[1][k]) <= 2e-3, (k, got[1][k], exp[1][k])
+
+
+def test_ragged_batch_smaller_than_workspace(ops):
+    """A last batch smaller than the workspace (GAN_functions.py:315-319)."""
+    from cycle_gan_rna_amd.engine import StepEngine
+    from cycle_gan_rna_amd.noise import HostReplayNoise
+    cfg = small_cfg(preprocess_type="log_normalized", nb_critic=1)
+    nets, xm, xh, lm, lh = make_problem(40, 40, 20, cfg)
+    cm, ch = O.centroid_table(xm, lm, 12), O.centroid_table(xh, lh, 12)
+    b = 13
+    tr = O.OracleTrainer(nets, cfg, cm, ch)
+    torch.manual_seed(5)
+    e = tr.iteration(0, xm[:b], xh[:b], lm[:b, None], lh[:b, None])
+    eng = StepEngine(nets, cfg, cm, ch, ops, 20)
+    torch.manual_seed(5)
+    g = eng.iteration(0, xm[:b].cuda(), xh[:b].cuda(), lm[:b, None].cuda(), lh[:b, None].cuda(), HostReplayNoise(ops.device))
+    for k in LOSS_KEYS:
+        assert rel(g[k], e[k]) <= 1e-4, (k, g[k], e[k])
