@@ -1,0 +1,181 @@
+"""Throughput of the CycleGAN training iteration on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is one pass of the reference's inner loop body (GAN_functions.py:298-419):
+a critic step, plus a generator step every nb_critic-th step (nb_critic = 4,
+GAN_main.py:56), on one batch of synthetic log-normalised expression that is
+already resident in HBM.  Workload (BASELINE.json configs[1]): 5000 genes per
+species, batch 512 per GPU, default architecture of GAN_main.py:47-77, 12 cell
+types.  N > 1: batch-sharded data parallel, 512 cells per rank (weak scaling).
+
+Prints one JSON line (rank 0) with the whole-job cells/s, the GEMM roofline
+measured with HIP events on the launch stream, and - at N = 1 - the CPU oracle
+timed on the host cores on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+G_GENES = 5000
+BATCH = 512
+N_TYPES = 12
+NB_CRITIC = 4
+F32_MFMA_PEAK_TFLOPS = 157.3      # dense float32 matrix peak of MI355X
+
+
+def algorithmic_gflop_per_cell_iteration(G, nb_critic=4, E=12):
+    """Necessary multiply-adds of one iteration per cell (2 FLOP each): generator
+    and critic passes with the reference's wasted sweeps excluded."""
+    Gf = G * 2048 + 2048 * 1024 + 1024 * 512 + 512 * 512 + 268 * 2048 + 2048 * 1024 + 1024 * 512 + 512 * G + 131072
+    D1 = (G + E) * 1024
+    Dr = 1024 * 512 + 512 * 256 + 256
+    Df = D1 + Dr
+    d_step = 2 * Gf + 6 * Df + 4 * (Df + Dr + E * 1024) + 2 * Df + 2 * (3 * D1 + 2 * Dr)
+    g_step = 12 * Gf - 4096 * G + 10 * Df
+    return 2.0 * (d_step + g_step / nb_critic) / 1e9
+
+
+def cpu_baseline(seconds_budget=20.0):
+    """The CPU oracle (a float32 restatement of the reference step on torch CPU
+    ops) on the same shapes: 1 generator step + 4 critic steps = 4 iterations."""
+    from oracle import cyclegan_oracle as O
+    from oracle import init_params
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
+    cfg = O.default_config(preprocess_type="log_normalized", batch_size=BATCH)
+    nets = init_params.build_nets(G_GENES, G_GENES, [N_TYPES], cfg, seed=0)
+    xm, _ = O.synthetic_expression(BATCH, G_GENES, N_TYPES, seed=1234)
+    xh, _ = O.synthetic_expression(BATCH, G_GENES, N_TYPES, seed=1235)
+    lm, lh = O.balanced_labels(BATCH, N_TYPES, 1), O.balanced_labels(BATCH, N_TYPES, 2)
+    tr = O.OracleTrainer(nets, cfg, O.centroid_table(xm, lm, N_TYPES), O.centroid_table(xh, lh, N_TYPES))
+    torch.manual_seed(1)
+    lm, lh = lm[:, None], lh[:, None]
+    tr.iteration(1, xm, xh, lm, lh)            # warm-up: one critic step
+    t0 = time.perf_counter()
+    iters = 0
+    while True:
+        for i in range(NB_CRITIC):
+            tr.iteration(i, xm, xh, lm, lh)
+        iters += NB_CRITIC
+        if time.perf_counter() - t0 > seconds_budget or iters >= 16:
+            break
+    dt = time.perf_counter() - t0
+    return dict(value=iters * BATCH / dt, unit="cells/s", cores=threads, kind="port",
+                sample=f"{iters} iterations (G={G_GENES}, B={BATCH}, nb_critic={NB_CRITIC}) of the float32 CPU oracle "
+                       f"in {dt:.1f} s, including the reference's discarded backward sweeps")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--genes", type=int, default=G_GENES)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local)
+
+    from cycle_gan_rna_amd.engine import StepEngine
+    from cycle_gan_rna_amd.noise import DeviceNoise
+    from cycle_gan_rna_amd.ops import HipOps
+    from oracle import cyclegan_oracle as O          # synthetic data + init recipe only
+    from oracle import init_params
+
+    G, B = a.genes, a.batch
+    cfg = O.default_config(preprocess_type="log_normalized", batch_size=B)
+    nets = init_params.build_nets(G, G, [N_TYPES], cfg, seed=0)          # same weights on every rank
+    n_cells = 16 * B
+    xm, lm = O.synthetic_expression(n_cells, G, N_TYPES, seed=1234 + 2 * rank)
+    xh, lh = O.synthetic_expression(n_cells, G, N_TYPES, seed=1235 + 2 * rank)
+    cm, ch = O.centroid_table(xm, lm, N_TYPES), O.centroid_table(xh, lh, N_TYPES)
+    ops = HipOps(dev)
+    eng = StepEngine(nets, cfg, cm, ch, ops, B)
+    xm, xh, lm, lh = xm.to(dev), xh.to(dev), lm[:, None].to(dev), lh[:, None].to(dev)
+    noise = DeviceNoise(dev, seed=1 + rank)
+
+    def step(i):
+        s = (i % 16) * B
+        noise.begin_step()
+        eng.d_step(xm[s:s + B], xh[s:s + B], lm[s:s + B], lh[s:s + B], noise)
+        if i % NB_CRITIC == 0:
+            eng.g_step(xm[s:s + B], xh[s:s + B], lm[s:s + B], lh[s:s + B], noise)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    losses = {**eng.d_losses(), **eng.g_losses()}
+    assert all(v == v and abs(v) < 1e30 for k, v in losses.items() if isinstance(v, float)), losses
+
+    roof = None
+    if not a.no_roofline and rank == 0:
+        # GEMM launches of NB_CRITIC iterations (4 critic + 1 generator step), each bracketed by HIP events
+        ops.begin_gemm_timing()
+        for i in range(NB_CRITIC):
+            step(i)
+        torch.cuda.synchronize()
+        n_launch, gemm_ms, exec_flop = ops.end_gemm_timing()
+        alg_flop = algorithmic_gflop_per_cell_iteration(G) * 1e9 * B * NB_CRITIC
+        achieved = alg_flop / (gemm_ms * 1e-3) / 1e12
+        roof = dict(bound="mfma", achieved=achieved, peak=F32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=achieved / F32_MFMA_PEAK_TFLOPS, traffic=None,
+                    kernel="gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", launches_per_iteration=n_launch / NB_CRITIC,
+                    avg_launch_us=gemm_ms * 1e3 / n_launch, gemm_ms_per_iteration=gemm_ms / NB_CRITIC,
+                    executed_tflops=exec_flop / (gemm_ms * 1e-3) / 1e12)
+    if world > 1:
+        dist.barrier()
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline()
+    if rank == 0:
+        line = {
+            "metric": "train cells/sec (G+D fwd/bwd/update)", "value": B * world * a.steps / dt, "unit": "cells/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"CycleGAN MLP, {G} genes per species, batch {B} per GPU, nb_critic {NB_CRITIC}, "
+                                   f"hidden 2048/1024/512, latent 256, {N_TYPES} cell types, log-normalised synthetic "
+                                   f"expression, float32 MFMA", "global_batch": B * world,
+                       "parallelism": f"dp{world}"},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

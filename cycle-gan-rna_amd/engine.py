@@ -64,6 +64,14 @@ class Arena:
         self.vmax = ops.zeros(off)
         self.lr_step = ops.zeros(2, dtype=torch.float64)
         self.step = 0
+        self.net_range = {}
+        for (net, _), (o, n, _) in self.offsets.items():
+            lo, hi = self.net_range.get(net, (o, o))
+            self.net_range[net] = (min(lo, o), max(hi, o + _pad4(n)))
+
+    def net_grad(self, net):
+        lo, hi = self.net_range[net]
+        return self.g[lo:hi]
 
     def view(self, buf, key):
         off, n, shape = self.offsets[key]
@@ -531,6 +539,11 @@ class StepEngine:
         self.var_out = Z(2)
         self.var_ws = Z(max((max(gm, gh) + 31) // 32, 1), dtype=torch.float64)
         self._d_scales_b = None
+        from .ddp import GradSync
+        self.sync = GradSync(ops.device)
+        self.g_tot = Z(10, dtype=torch.float64)
+        self.g_slots = ops.to_device(torch.arange(S_ADV_H, S_ADV_H + 10, dtype=torch.int32))
+        self.g_ones = ops.to_device(torch.ones(10, dtype=torch.float64))
 
     # ---- optimizer ---------------------------------------------------------------
     def set_lr(self, lr):
@@ -566,6 +579,8 @@ class StepEngine:
             ops.gp_interp(xhat, real, fake, alpha)
             dp.forward(xhat, fake_lab, noise)
             dp.gp_backward(cfg["lambda_gp"], self.red, s0 + 2)
+            self.sync.launch(self.arena_d.net_grad(name))
+        self.sync.wait()
         self._adam(self.arena_d, self.lr_d)
         if self._d_scales_b != b:
             lam = float(cfg["lambda_gp"])
@@ -616,13 +631,22 @@ class StepEngine:
         ops.reduce_kl(red, S_KL_H, A.ml[:b])                               # :375-376
         ops.reduce_kl(red, S_KL_M, Bp.ml[:b])
         L = cfg["latent_dim"]
+        if self.sync.enabled:
+            # every rank must derive the same loss scales: replace the local loss sums by their sum over ranks
+            ops.sum_parts(self.g_tot, red, self.g_slots, self.g_ones)
+            self.sync.sum_scalars(self.g_tot)
+            red[0][S_ADV_H:S_ADV_H + 10, 0] = self.g_tot.to(red[0].dtype)
+            red[1][S_ADV_H:S_ADV_H + 10] = 1
+        bl = b
+        b = b * self.sync.world          # normalisation of the global-batch losses
         desc = dict(
             terms=[[(S_ADV_H, -1.0 / b), (S_ADV_M, -1.0 / b)],
                    [(S_CYC_M, 1.0 / (b * gm)), (S_CYC_H, 1.0 / (b * gh))],
                    [(S_CT_H, 1.0 / (b * gh)), (S_CT_M, 1.0 / (b * gm))],
-                   [(S_FM_H, 0.5 / 256), (S_FM_M, 0.5 / 256)],
+                   [(S_FM_H, 0.5 / 256 / self.sync.world), (S_FM_M, 0.5 / 256 / self.sync.world)],
                    [(S_KL_H, -0.5 / (b * L)), (S_KL_M, -0.5 / (b * L))]],
             ema_alpha=0.3)
+        b = bl
         desc["lambda"] = [float(cfg["lambda_adv"]), float(cfg["lambda_cycle"]), float(cfg["lambda_celltype"]),
                           float(cfg["lambda_fm"]), float(cfg["lambda_kl"])]
         ops.gloss_finalize(self.ema, self.gloss, self.coef, red, desc)     # :380-406
@@ -644,7 +668,10 @@ class StepEngine:
         ops.l1_bwd(drh, recov_human, human, coef, 1, 1.0 / (b * gh))
         Rh.backward(drh, need_dx=True, dx_out=dfm, dx_accumulate=True)
         A.backward(dfh, kl=(coef, 4, 1.0))
+        self.sync.launch(self.arena_g.net_grad("g_m2h"))
         Bp.backward(dfm, kl=(coef, 4, 1.0))
+        self.sync.launch(self.arena_g.net_grad("g_h2m"))
+        self.sync.wait()
         self._adam(self.arena_g, self.lr_g)
         ops.colvar_mean(self.var_out[0:1], self.var_ws, fake_human)        # :418-419
         ops.colvar_mean(self.var_out[1:2], self.var_ws, fake_mouse)

@@ -47,6 +47,17 @@ class HipOps:
             raise RuntimeError("cycle-gan-rna_amd needs a HIP device (torch.cuda.is_available() is False)")
         self.lib = _lib.load()
         self.device = torch.device(device if device is not None else "cuda:0")
+        self._gemm_events = None
+
+    # -- measurement: HIP events around every GEMM launch, on the launch stream ----------
+    def begin_gemm_timing(self):
+        self._gemm_events = []
+
+    def end_gemm_timing(self):
+        """Returns (launches, total milliseconds, executed FLOP) since begin_gemm_timing()."""
+        torch.cuda.synchronize(self.device)
+        ev, self._gemm_events = self._gemm_events, None
+        return len(ev), sum(a.elapsed_time(b) for a, b, _ in ev), sum(f for _, _, f in ev)
 
     # -- plumbing -------------------------------------------------------------
     def _stream(self):
@@ -76,9 +87,15 @@ class HipOps:
             assert tuple(E.shape) == (M, N)
         if aux is not None:
             assert tuple(aux.shape) == (M, N)
+        if self._gemm_events is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(self.device))
         st = self.lib.cg_gemm(_ptr(Cm), _ld(Cm), _ptr(A), _ld(A), _ptr(B), _ld(B), M, N, K, int(transA), int(transB),
                               0, _ptr(bias), epi, _ptr(E), _ld(E), _ptr(aux), _ld(aux), float(slope),
                               int(accumulate), self._stream())
+        if self._gemm_events is not None:
+            e1.record(torch.cuda.current_stream(self.device))
+            self._gemm_events.append((e0, e1, 2.0 * M * N * K))
         _lib.check(st, "cg_gemm")
 
     # -- BatchNorm --------------------------------------------------------------
