@@ -69,7 +69,28 @@ def test_iterations_match_oracle(ops, ptype, gm, gh, B):
         ftol = 1e-4 if i == 0 else 3e-2
         assert rel(g["fake_human"], e["fake_human"]) <= ftol, (i, rel(g["fake_human"], e["fake_human"]))
         assert rel(g["fake_mouse"], e["fake_mouse"]) <= ftol, (i, rel(g["fake_mouse"], e["fake_mouse"]))
-    # parameter updates
+    check_updates(nets, tr, eng, 5e-2)
+
+
+def oracle_vmax(tr):
+    """(net, key) -> Adam's running max of the squared gradient in the oracle."""
+    out = {}
+    gm, gh = O.param_names(tr.nets["g_m2h"]), O.param_names(tr.nets["g_h2m"])
+    for (n, k), st in zip([("g_m2h", k) for k in gm] + [("g_h2m", k) for k in gh], tr.opt_g.state):
+        out[(n, k)] = st["vmax"]
+    for n, opt in (("d_m", tr.opt_dm), ("d_h", tr.opt_dh)):
+        for k, st in zip(O.param_names(tr.nets[n]), opt.state):
+            out[(n, k)] = st["vmax"]
+    return out
+
+
+def check_updates(nets, tr, eng, tol):
+    """Relative L2 of the applied update, over the elements whose gradient is not
+    rounding noise.  Adam divides every gradient by its own magnitude, so an
+    element whose true gradient is zero (|g| ~ 1e-9 of the tensor's largest)
+    moves by +-lr with a sign decided by summation order; such elements
+    (sqrt(vmax) below 1e-5 of the tensor's maximum in the oracle) are excluded."""
+    vmax = oracle_vmax(tr)
     for n in ("g_m2h", "g_h2m", "d_m", "d_h"):
         sd = eng.state_dict(n)
         for k, v in sd.items():
@@ -81,8 +102,12 @@ def test_iterations_match_oracle(ops, ptype, gm, gh, B):
             ref = tr.nets[n][k].detach()
             if k.endswith(("running_mean", "running_var")):
                 assert rel(v, ref) <= 5e-3, (n, k)
-            else:
-                assert update_rel_l2(v, ref, nets[n][k]) <= 5e-2, (n, k, update_rel_l2(v, ref, nets[n][k]))
+                continue
+            g = vmax[(n, k)].sqrt()
+            mask = g > 1e-5 * g.max()
+            assert float(mask.float().mean()) > 0.5, (n, k)
+            err = update_rel_l2(v[mask], ref[mask], nets[n][k][mask])
+            assert err <= tol, (n, k, err)
 
 
 def test_default_hidden_dims_one_iteration(ops):
