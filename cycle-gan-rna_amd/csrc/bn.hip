@@ -1,16 +1,39 @@
 // Train-mode BatchNorm1d (forward, backward, backward-of-backward) fused with
-// the activation / dropout that follows it.  HBM/L2-bound column kernels: a
-// block owns a strip of 32 columns (one 128-byte line per row) and walks the M
-// rows with 8 row lanes; column statistics are accumulated in float64 and
-// combined across the row lanes through LDS, then the same block applies them.
+// the activation / dropout that follows it.  HBM/L2-bound column kernels.
+//
+// Geometry: a block owns a strip of 32 columns (one 128-byte line per row) and
+// a chunk of rows, walked by 8 row lanes.  Each op is two launches over the
+// same (strips x row-chunks) grid:
+//   stats : per-block column sums in float64 -> workspace[stat][chunk][col]
+//   apply : every block re-adds the (<= 64) chunk partials of its 32 columns in
+//           chunk order (deterministic, no atomics), derives the column
+//           statistics and applies them to its rows
+// so tall-skinny (8192 x 16) and short-wide (512 x 2048) inputs both spread
+// over hundreds of workgroups.
 #include "common.h"
 
 namespace {
 
 constexpr int CW = 32;   // columns per block
 constexpr int RL = 8;    // row lanes per block
+constexpr int MAX_RC = 64;
 
-// Sum `NS` per-thread doubles over the 8 row lanes of each column.
+struct Geo {
+  int strips, rc, rows;  // column strips, row chunks, rows per chunk
+};
+static inline Geo geo(int M, int N) {
+  Geo g;
+  g.strips = (N + CW - 1) / CW;
+  int rc = 512 / g.strips;
+  if (rc > MAX_RC) rc = MAX_RC;
+  if (rc > (M + RL - 1) / RL) rc = (M + RL - 1) / RL;
+  if (rc < 1) rc = 1;
+  g.rows = ((M + rc - 1) / rc + RL - 1) / RL * RL;
+  g.rc = (M + g.rows - 1) / g.rows;
+  return g;
+}
+
+// Sum `NS` per-thread doubles over the 8 row lanes of each column; result in every lane of the column.
 template <int NS>
 __device__ __forceinline__ void strip_reduce(double (&s)[NS], double* lds /* NS*RL*CW */) {
   const int c = threadIdx.x & (CW - 1), r = threadIdx.x / CW;
@@ -27,29 +50,73 @@ __device__ __forceinline__ void strip_reduce(double (&s)[NS], double* lds /* NS*
   __syncthreads();
 }
 
-__global__ void __launch_bounds__(256) bn_fwd_kernel(float* Y, int ldy, const float* X, int ldx, int M, int N,
-                                                     const float* gamma, const float* beta, float eps,
-                                                     float* mean_out, float* invstd_out, float* rmean, float* rvar,
-                                                     float momentum, float slope, const float* mask, int ldmask,
-                                                     float* pm_out, int ldpm, u16* ybf, int ldybf) {
+// Write this block's column sums to the workspace.
+template <int NS>
+__device__ __forceinline__ void put_partials(double (&s)[NS], double* lds, double* ws, int N, int col) {
+  strip_reduce<NS>(s, lds);
+  if (threadIdx.x < CW && col < N) {
+#pragma unroll
+    for (int i = 0; i < NS; ++i) ws[((size_t)i * gridDim.y + blockIdx.y) * N + col] = s[i];
+  }
+}
+
+// Re-add the chunk partials of this block's columns (row lanes split the chunks).
+template <int NS>
+__device__ __forceinline__ void get_totals(double (&s)[NS], double* lds, const double* ws, int N, int col) {
+  const int r = threadIdx.x / CW;
+#pragma unroll
+  for (int i = 0; i < NS; ++i) s[i] = 0.0;
+  if (col < N)
+    for (int ch = r; ch < (int)gridDim.y; ch += RL) {
+#pragma unroll
+      for (int i = 0; i < NS; ++i) s[i] += ws[((size_t)i * gridDim.y + ch) * N + col];
+    }
+  strip_reduce<NS>(s, lds);
+}
+
+#define BN_COMMON                                              \
+  const int c = threadIdx.x & (CW - 1), r0 = threadIdx.x / CW; \
+  const int col = blockIdx.x * CW + c;                         \
+  const bool ok = col < N;                                     \
+  const int m0 = blockIdx.y * rows;                            \
+  const int m1 = min(M, m0 + rows);
+
+__device__ __forceinline__ float pm_of(const float* Y, int ldy, const float* PM, int ldpm, float slope, int m, int col) {
+  if (PM) return PM[(size_t)m * ldpm + col];
+  if (Y) return Y[(size_t)m * ldy + col] > 0.f ? 1.f : slope;
+  return 1.f;
+}
+
+// ---------------- forward ----------------
+__global__ void __launch_bounds__(256) bn_fwd_stats(double* ws, const float* X, int ldx, int M, int N, int rows) {
   __shared__ double lds[2 * RL * CW];
-  const int c = threadIdx.x & (CW - 1), r0 = threadIdx.x / CW;
-  const int col = blockIdx.x * CW + c;
-  const bool ok = col < N;
+  BN_COMMON
   double s[2] = {0.0, 0.0};
   if (ok)
-    for (int m = r0; m < M; m += RL) {
+    for (int m = m0 + r0; m < m1; m += RL) {
       const double x = X[(size_t)m * ldx + col];
       s[0] += x;
       s[1] += x * x;
     }
-  strip_reduce<2>(s, lds);
+  put_partials<2>(s, lds, ws, N, col);
+}
+
+__global__ void __launch_bounds__(256) bn_fwd_apply(const double* ws, float* Y, int ldy, const float* X, int ldx, int M,
+                                                    int N, int rows, const float* gamma, const float* beta, float eps,
+                                                    float* mean_out, float* invstd_out, float* rmean, float* rvar,
+                                                    float momentum, float slope, const float* mask, int ldmask,
+                                                    float* pm_out, int ldpm, u16* ybf, int ldybf) {
+  __shared__ double lds[2 * RL * CW];
+  BN_COMMON
+  double s[2];
+  get_totals<2>(s, lds, ws, N, col);
+  if (!ok) return;
   const double mean_d = s[0] / M;
   double var_d = s[1] / M - mean_d * mean_d;
   if (var_d < 0.0) var_d = 0.0;
   const float mean = (float)mean_d;
   const float invstd = (float)(1.0 / sqrt(var_d + (double)eps));
-  if (ok && r0 == 0) {
+  if (blockIdx.y == 0 && r0 == 0) {
     mean_out[col] = mean;
     invstd_out[col] = invstd;
     if (rmean) rmean[col] = (1.f - momentum) * rmean[col] + momentum * mean;
@@ -58,9 +125,8 @@ __global__ void __launch_bounds__(256) bn_fwd_kernel(float* Y, int ldy, const fl
       rvar[col] = (1.f - momentum) * rvar[col] + momentum * unb;
     }
   }
-  if (!ok) return;
   const float ga = gamma[col], be = beta[col];
-  for (int m = r0; m < M; m += RL) {
+  for (int m = m0 + r0; m < m1; m += RL) {
     const float xh = (X[(size_t)m * ldx + col] - mean) * invstd;
     const float h = xh * ga + be;
     float pm = h > 0.f ? 1.f : slope;
@@ -85,76 +151,90 @@ __global__ void __launch_bounds__(256) bn_eval_kernel(float* Y, int ldy, const f
   }
 }
 
-__device__ __forceinline__ float pm_of(const float* Y, int ldy, const float* PM, int ldpm, float slope, int m, int col) {
-  if (PM) return PM[(size_t)m * ldpm + col];
-  if (Y) return Y[(size_t)m * ldy + col] > 0.f ? 1.f : slope;
-  return 1.f;
-}
-
-__global__ void __launch_bounds__(256) bn_bwd_kernel(float* dX, int lddx, const float* dY, int lddy, const float* X,
-                                                     int ldx, const float* Y, int ldy, const float* PM, int ldpm,
-                                                     const float* mean, const float* invstd, const float* gamma,
-                                                     float* dgamma, float* dbeta, int accumulate, float* gbar_out,
-                                                     float* gxbar_out, float slope, int M, int N) {
+// ---------------- backward ----------------
+__global__ void __launch_bounds__(256) bn_bwd_stats(double* ws, const float* dY, int lddy, const float* X, int ldx,
+                                                    const float* Y, int ldy, const float* PM, int ldpm,
+                                                    const float* mean, const float* invstd, float slope, int M, int N,
+                                                    int rows) {
   __shared__ double lds[2 * RL * CW];
-  const int c = threadIdx.x & (CW - 1), r0 = threadIdx.x / CW;
-  const int col = blockIdx.x * CW + c;
-  const bool ok = col < N;
+  BN_COMMON
   const float mu = ok ? mean[col] : 0.f, is = ok ? invstd[col] : 0.f;
   double s[2] = {0.0, 0.0};
   if (ok)
-    for (int m = r0; m < M; m += RL) {
+    for (int m = m0 + r0; m < m1; m += RL) {
       const float g = dY[(size_t)m * lddy + col] * pm_of(Y, ldy, PM, ldpm, slope, m, col);
       const float xh = (X[(size_t)m * ldx + col] - mu) * is;
       s[0] += g;
       s[1] += (double)g * xh;
     }
-  strip_reduce<2>(s, lds);
+  put_partials<2>(s, lds, ws, N, col);
+}
+
+__global__ void __launch_bounds__(256) bn_bwd_apply(const double* ws, float* dX, int lddx, const float* dY, int lddy,
+                                                    const float* X, int ldx, const float* Y, int ldy, const float* PM,
+                                                    int ldpm, const float* mean, const float* invstd,
+                                                    const float* gamma, float* dgamma, float* dbeta, int accumulate,
+                                                    float* gbar_out, float* gxbar_out, float slope, int M, int N,
+                                                    int rows) {
+  __shared__ double lds[2 * RL * CW];
+  BN_COMMON
+  double s[2];
+  get_totals<2>(s, lds, ws, N, col);
   if (!ok) return;
+  const float mu = mean[col], is = invstd[col];
   const float gbar = (float)(s[0] / M), gxbar = (float)(s[1] / M);
-  if (r0 == 0) {
+  if (blockIdx.y == 0 && r0 == 0) {
     if (dbeta) dbeta[col] = (accumulate ? dbeta[col] : 0.f) + (float)s[0];
     if (dgamma) dgamma[col] = (accumulate ? dgamma[col] : 0.f) + (float)s[1];
     if (gbar_out) gbar_out[col] = gbar;
     if (gxbar_out) gxbar_out[col] = gxbar;
   }
   const float k = is * gamma[col];
-  for (int m = r0; m < M; m += RL) {
+  for (int m = m0 + r0; m < m1; m += RL) {
     const float g = dY[(size_t)m * lddy + col] * pm_of(Y, ldy, PM, ldpm, slope, m, col);
     const float xh = (X[(size_t)m * ldx + col] - mu) * is;
     dX[(size_t)m * lddx + col] = k * (g - gbar - xh * gxbar);
   }
 }
 
-__global__ void __launch_bounds__(256) bn_bwd_bwd_kernel(float* Vu, int ldvu, float* Vh, int ldvh, float* dgamma,
-                                                         int accumulate, const float* W, int ldw, const float* U1,
-                                                         int ldu, const float* X, int ldx, const float* mean,
-                                                         const float* invstd, const float* gamma, const float* ubar,
-                                                         const float* mbar, int M, int N) {
+// ---------------- backward of backward ----------------
+__global__ void __launch_bounds__(256) bn_bb_stats(double* ws, const float* W, int ldw, const float* U1, int ldu,
+                                                   const float* X, int ldx, const float* mean, const float* invstd,
+                                                   int M, int N, int rows) {
   __shared__ double lds[3 * RL * CW];
-  const int c = threadIdx.x & (CW - 1), r0 = threadIdx.x / CW;
-  const int col = blockIdx.x * CW + c;
-  const bool ok = col < N;
+  BN_COMMON
   const float mu = ok ? mean[col] : 0.f, is = ok ? invstd[col] : 0.f;
   double s[3] = {0.0, 0.0, 0.0};
   if (ok)
-    for (int m = r0; m < M; m += RL) {
+    for (int m = m0 + r0; m < m1; m += RL) {
       const float w = W[(size_t)m * ldw + col];
       const float xh = (X[(size_t)m * ldx + col] - mu) * is;
       s[0] += w;
       s[1] += (double)w * xh;
       s[2] += (double)w * U1[(size_t)m * ldu + col];
     }
-  strip_reduce<3>(s, lds);
+  put_partials<3>(s, lds, ws, N, col);
+}
+
+__global__ void __launch_bounds__(256) bn_bb_apply(const double* ws, float* Vu, int ldvu, float* Vh, int ldvh,
+                                                   float* dgamma, int accumulate, const float* W, int ldw,
+                                                   const float* U1, int ldu, const float* X, int ldx,
+                                                   const float* mean, const float* invstd, const float* gamma,
+                                                   const float* ubar, const float* mbar, int M, int N, int rows) {
+  __shared__ double lds[3 * RL * CW];
+  BN_COMMON
+  double s[3];
+  get_totals<3>(s, lds, ws, N, col);
   if (!ok) return;
+  const float mu = mean[col], is = invstd[col];
   const float wbar = (float)(s[0] / M), r = (float)(s[1] / M), q = (float)(s[2] / M);
   const float ub = ubar[col], mb = mbar[col], ga = gamma[col];
-  if (r0 == 0 && dgamma) {
+  if (blockIdx.y == 0 && r0 == 0 && dgamma) {
     const float d = (float)((double)M * is * ((double)q - (double)wbar * ub - (double)r * mb));
     dgamma[col] = (accumulate ? dgamma[col] : 0.f) + d;
   }
   const float k1 = is * ga, k2 = -is * is * ga, k3 = q - wbar * ub - 3.f * mb * r;
-  for (int m = r0; m < M; m += RL) {
+  for (int m = m0 + r0; m < m1; m += RL) {
     const float w = W[(size_t)m * ldw + col];
     const float u1 = U1[(size_t)m * ldu + col];
     const float xh = (X[(size_t)m * ldx + col] - mu) * is;
@@ -165,15 +245,26 @@ __global__ void __launch_bounds__(256) bn_bwd_bwd_kernel(float* Vu, int ldvu, fl
 
 }  // namespace
 
+extern "C" size_t cg_bn_workspace_bytes(int M, int N) {
+  if (M <= 0 || N <= 0) return 0;
+  const Geo g = geo(M, N);
+  return (size_t)3 * g.rc * N * sizeof(double);
+}
+
 extern "C" int cg_bn_fwd(float* Y, int ldy, const float* X, int ldx, int M, int N, const float* gamma,
                          const float* beta, float eps, float* mean_out, float* invstd_out, float* running_mean,
                          float* running_var, float momentum, float slope, const float* mask, int ldmask,
-                         float* pm_out, int ldpm, void* ybf16, int ldybf16, void* stream) {
+                         float* pm_out, int ldpm, void* ybf16, int ldybf16, void* workspace, size_t workspace_bytes,
+                         void* stream) {
   if (!Y || !X || !gamma || !beta || !mean_out || !invstd_out || M <= 0 || N <= 0) return CG_ERR_BAD_ARG;
   if (ldy < N || ldx < N || (mask && ldmask < N) || (pm_out && ldpm < N) || (ybf16 && ldybf16 < N)) return CG_ERR_BAD_ARG;
-  hipLaunchKernelGGL(bn_fwd_kernel, dim3((N + CW - 1) / CW), dim3(256), 0, (hipStream_t)stream, Y, ldy, X, ldx, M, N,
-                     gamma, beta, eps, mean_out, invstd_out, running_mean, running_var, momentum, slope, mask, ldmask,
-                     pm_out, ldpm, (u16*)ybf16, ldybf16);
+  if (!workspace || workspace_bytes < cg_bn_workspace_bytes(M, N)) return CG_ERR_WORKSPACE;
+  const Geo g = geo(M, N);
+  dim3 grid(g.strips, g.rc);
+  hipLaunchKernelGGL(bn_fwd_stats, grid, dim3(256), 0, (hipStream_t)stream, (double*)workspace, X, ldx, M, N, g.rows);
+  hipLaunchKernelGGL(bn_fwd_apply, grid, dim3(256), 0, (hipStream_t)stream, (const double*)workspace, Y, ldy, X, ldx,
+                     M, N, g.rows, gamma, beta, eps, mean_out, invstd_out, running_mean, running_var, momentum, slope,
+                     mask, ldmask, pm_out, ldpm, (u16*)ybf16, ldybf16);
   return cg_launch_status();
 }
 
@@ -192,23 +283,34 @@ extern "C" int cg_bn_eval(float* Y, int ldy, const float* X, int ldx, int M, int
 extern "C" int cg_bn_bwd(float* dX, int lddx, const float* dY, int lddy, const float* X, int ldx, const float* Y,
                          int ldy, const float* PM, int ldpm, const float* mean, const float* invstd,
                          const float* gamma, float* dgamma, float* dbeta, int accumulate, float* gbar_out,
-                         float* gxbar_out, float slope, int M, int N, void* stream) {
+                         float* gxbar_out, float slope, int M, int N, void* workspace, size_t workspace_bytes,
+                         void* stream) {
   if (!dX || !dY || !X || !mean || !invstd || !gamma || M <= 0 || N <= 0) return CG_ERR_BAD_ARG;
   if (lddx < N || lddy < N || ldx < N || (Y && ldy < N) || (PM && ldpm < N)) return CG_ERR_BAD_ARG;
-  hipLaunchKernelGGL(bn_bwd_kernel, dim3((N + CW - 1) / CW), dim3(256), 0, (hipStream_t)stream, dX, lddx, dY, lddy, X,
-                     ldx, Y, ldy, PM, ldpm, mean, invstd, gamma, dgamma, dbeta, accumulate, gbar_out, gxbar_out, slope,
-                     M, N);
+  if (!workspace || workspace_bytes < cg_bn_workspace_bytes(M, N)) return CG_ERR_WORKSPACE;
+  const Geo g = geo(M, N);
+  dim3 grid(g.strips, g.rc);
+  hipLaunchKernelGGL(bn_bwd_stats, grid, dim3(256), 0, (hipStream_t)stream, (double*)workspace, dY, lddy, X, ldx, Y,
+                     ldy, PM, ldpm, mean, invstd, slope, M, N, g.rows);
+  hipLaunchKernelGGL(bn_bwd_apply, grid, dim3(256), 0, (hipStream_t)stream, (const double*)workspace, dX, lddx, dY,
+                     lddy, X, ldx, Y, ldy, PM, ldpm, mean, invstd, gamma, dgamma, dbeta, accumulate, gbar_out,
+                     gxbar_out, slope, M, N, g.rows);
   return cg_launch_status();
 }
 
 extern "C" int cg_bn_bwd_bwd(float* V_u1, int ldvu, float* V_h0, int ldvh, float* dgamma, int accumulate,
                              const float* W, int ldw, const float* U1, int ldu, const float* X, int ldx,
                              const float* mean, const float* invstd, const float* gamma, const float* ubar,
-                             const float* mbar, int M, int N, void* stream) {
+                             const float* mbar, int M, int N, void* workspace, size_t workspace_bytes, void* stream) {
   if (!V_u1 || !V_h0 || !W || !U1 || !X || !mean || !invstd || !gamma || !ubar || !mbar || M <= 0 || N <= 0)
     return CG_ERR_BAD_ARG;
   if (ldvu < N || ldvh < N || ldw < N || ldu < N || ldx < N) return CG_ERR_BAD_ARG;
-  hipLaunchKernelGGL(bn_bwd_bwd_kernel, dim3((N + CW - 1) / CW), dim3(256), 0, (hipStream_t)stream, V_u1, ldvu, V_h0,
-                     ldvh, dgamma, accumulate, W, ldw, U1, ldu, X, ldx, mean, invstd, gamma, ubar, mbar, M, N);
+  if (!workspace || workspace_bytes < cg_bn_workspace_bytes(M, N)) return CG_ERR_WORKSPACE;
+  const Geo g = geo(M, N);
+  dim3 grid(g.strips, g.rc);
+  hipLaunchKernelGGL(bn_bb_stats, grid, dim3(256), 0, (hipStream_t)stream, (double*)workspace, W, ldw, U1, ldu, X, ldx,
+                     mean, invstd, M, N, g.rows);
+  hipLaunchKernelGGL(bn_bb_apply, grid, dim3(256), 0, (hipStream_t)stream, (const double*)workspace, V_u1, ldvu, V_h0,
+                     ldvh, dgamma, accumulate, W, ldw, U1, ldu, X, ldx, mean, invstd, gamma, ubar, mbar, M, N, g.rows);
   return cg_launch_status();
 }

@@ -56,16 +56,32 @@ __global__ void embed_gather_kernel(float* out, int ldo, const float* table, int
   out[(size_t)m * ldo + e] = table[t * E + e];
 }
 
-// One thread per table entry walks all rows: deterministic, and the table is tiny.
-__global__ void embed_scatter_kernel(float* dtable, int E, const float* dout, int lddo, const int64_t* labels,
-                                     int lstride, int M, int n_types, int accumulate) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_types * E) return;
-  const int t = i / E, e = i % E;
-  float s = 0.f;
-  for (int m = 0; m < M; ++m)
-    if (labels[(size_t)m * lstride] == t) s += dout[(size_t)m * lddo + e];
-  dtable[i] = (accumulate ? dtable[i] : 0.f) + s;
+// One block per table row (cell type): 8 row lanes x 32 column lanes walk the batch, then the row lanes are
+// combined through LDS in a fixed order (deterministic; embedding widths up to 128).
+__global__ void __launch_bounds__(256) embed_scatter_kernel(float* dtable, int E, const float* dout, int lddo,
+                                                            const int64_t* labels, int lstride, int M, int n_types,
+                                                            int accumulate) {
+  __shared__ float lds[8][128];
+  const int t = blockIdx.x;
+  const int el = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int m = rl; m < M; m += 8) {
+    if (labels[(size_t)m * lstride] != t) continue;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int e = el + 32 * u;
+      if (e < E) acc[u] += dout[(size_t)m * lddo + e];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 4; ++u) lds[rl][el + 32 * u] = acc[u];
+  __syncthreads();
+  for (int e = threadIdx.x; e < E; e += 256) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) s += lds[r][e];
+    dtable[t * E + e] = (accumulate ? dtable[t * E + e] : 0.f) + s;
+  }
 }
 
 __global__ void reparam_fwd_kernel(float* z, int ldz, const float* ml, int ldml, const float* eps, int M, int L) {
@@ -379,8 +395,9 @@ extern "C" int cg_embed_gather(float* out, int ldo, const float* table, int E, c
 extern "C" int cg_embed_scatter(float* dtable, int E, const float* dout, int lddo, const int64_t* labels, int lstride,
                                 int M, int n_types, int accumulate, void* stream) {
   if (!dtable || !dout || !labels || E <= 0 || M < 0 || lddo < E || lstride < 1 || n_types <= 0) return CG_ERR_BAD_ARG;
-  hipLaunchKernelGGL(embed_scatter_kernel, dim3((n_types * E + 63) / 64), dim3(64), 0, ST, dtable, E, dout, lddo,
-                     labels, lstride, M, n_types, accumulate);
+  if (E > 128) return CG_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(embed_scatter_kernel, dim3(n_types), dim3(256), 0, ST, dtable, E, dout, lddo, labels, lstride, M,
+                     n_types, accumulate);
   return cg_launch_status();
 }
 

@@ -27,6 +27,8 @@ struct GemmArgs {
   int epi, accumulate;
   float slope;
   int tiles_n;
+  int kt_per_split;   // K slabs handled by one blockIdx.y (split-K); all of them when gridDim.y == 1
+  float* ws;          // split-K: partial results [gridDim.y][M][N]
 };
 
 constexpr int BK = 32;
@@ -110,16 +112,18 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
 
   Stager<BM, A_MMAJ, VEC> sa;
   Stager<BN, B_MMAJ, VEC> sb;
-  const int nk = (g.K + BK - 1) / BK;
+  const int nk_all = (g.K + BK - 1) / BK;
+  const int kt0 = blockIdx.y * g.kt_per_split;
+  const int nk = min(nk_all, kt0 + g.kt_per_split);
 
-  sa.load(g.A, g.lda, bm, g.M, 0, g.K);
-  sb.load(g.B, g.ldb, bn, g.N, 0, g.K);
+  sa.load(g.A, g.lda, bm, g.M, kt0 * BK, g.K);
+  sb.load(g.B, g.ldb, bn, g.N, kt0 * BK, g.K);
   sa.store(smem);
   sb.store(smem + A_ELEMS);
   __syncthreads();
 
   int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
+  for (int kt = kt0; kt < nk; ++kt) {
     if (kt + 1 < nk) {
       sa.load(g.A, g.lda, bm, g.M, (kt + 1) * BK, g.K);
       sb.load(g.B, g.ldb, bn, g.N, (kt + 1) * BK, g.K);
@@ -167,6 +171,22 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
   }
 
   // epilogue: 32x32 accumulator, col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  if (gridDim.y > 1) {   // split-K: raw partial sums, combined by splitk_reduce_kernel
+    float* wsp = g.ws + (size_t)blockIdx.y * g.M * g.N;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = bn + wn + 32 * j + li;
+        if (col >= g.N) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = bm + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (row < g.M) wsp[(size_t)row * g.N + col] = acc[i][j][r];
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -195,12 +215,28 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
     }
 }
 
+// C = (accumulate ? C : 0) + bias + sum over splits of the partials, in split order.
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(float* C, int ldc, const float* ws, int splits, int M,
+                                                            int N, const float* bias, int accumulate) {
+  const size_t total = (size_t)M * N;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int m = (int)(i / N), n = (int)(i % N);
+    float s = bias ? bias[n] : 0.f;
+    for (int k = 0; k < splits; ++k) s += ws[(size_t)k * total + i];
+    float* cp = C + (size_t)m * ldc + n;
+    *cp = accumulate ? *cp + s : s;
+  }
+}
+
 template <int BM, int BN>
-int launch_f32(const GemmArgs& g, int transA, int transB, bool vec, hipStream_t st) {
+int launch_f32(const GemmArgs& g, int transA, int transB, bool vec, hipStream_t st, int splits = 1) {
   GemmArgs a = g;
   const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
   a.tiles_n = tn;
-  dim3 grid(tm * tn), block(256);
+  const int nk = (g.K + BK - 1) / BK;
+  a.kt_per_split = (nk + splits - 1) / splits;
+  splits = (nk + a.kt_per_split - 1) / a.kt_per_split;   // no empty split
+  dim3 grid(tm * tn, splits), block(256);
 #define CG_LAUNCH(TA, TB)                                                              \
   do {                                                                                 \
     if (vec)                                                                           \
@@ -213,6 +249,13 @@ int launch_f32(const GemmArgs& g, int transA, int transB, bool vec, hipStream_t 
   else if (transA && !transB) CG_LAUNCH(true, false);
   else CG_LAUNCH(true, true);
 #undef CG_LAUNCH
+  if (splits > 1) {
+    const size_t total = (size_t)g.M * g.N;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, g.C, g.ldc, g.ws, splits, g.M, g.N,
+                       g.bias, g.accumulate);
+  }
   return cg_launch_status();
 }
 
@@ -221,7 +264,7 @@ int launch_f32(const GemmArgs& g, int transA, int transB, bool vec, hipStream_t 
 extern "C" int cg_gemm(float* C, int ldc, const void* A, int lda, const void* B, int ldb,
                        int M, int N, int K, int transA, int transB, int dtype,
                        const float* bias, int epi, const float* E, int lde, float* aux, int ldaux,
-                       float slope, int accumulate, void* stream) {
+                       float slope, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
   if (!C || !A || !B || M < 0 || N < 0 || K < 0) return CG_ERR_BAD_ARG;
   if (M == 0 || N == 0) return CG_OK;
   if (epi < CG_EPI_NONE || epi > CG_EPI_MUL) return CG_ERR_BAD_ARG;
@@ -236,12 +279,25 @@ extern "C" int cg_gemm(float* C, int ldc, const void* A, int lda, const void* B,
   if (dtype != CG_F32) return CG_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   GemmArgs g{(const float*)A, (const float*)B, C, bias, E, aux, M, N, K, lda, ldb, ldc, lde, ldaux,
-             epi, accumulate, slope, 0};
+             epi, accumulate, slope, 0, 1 << 30, (float*)workspace};
   const bool vec = (((uintptr_t)A | (uintptr_t)B) % 16 == 0) && (lda % 4 == 0) && (ldb % 4 == 0);
   // Tile choice: the largest tile that still yields about one block per CU.
   const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
   const long t12864 = (long)((M + 127) / 128) * ((N + 63) / 64);
   if (t128 >= 192) return launch_f32<128, 128>(g, transA, transB, vec, st);
   if (t12864 >= 192) return launch_f32<128, 64>(g, transA, transB, vec, st);
-  return launch_f32<64, 64>(g, transA, transB, vec, st);
+  // Few output tiles and a long reduction (weight gradients of the 16x16 token layers: K = 16*batch;
+  // 512-row layers with 512 or 1024 outputs): split K over blockIdx.y so the chip is filled.
+  int splits = 1;
+  const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64);
+  const int nk = (K + BK - 1) / BK;
+  if (epi == CG_EPI_NONE && workspace && t64 <= 96 && nk >= 8) {
+    splits = (int)(256 / t64);
+    if (splits > nk / 4) splits = nk / 4;
+    if (splits > 64) splits = 64;
+    const size_t per = (size_t)M * N * sizeof(float);
+    if ((size_t)splits * per > workspace_bytes) splits = (int)(workspace_bytes / per);
+    if (splits < 2) splits = 1;
+  }
+  return launch_f32<64, 64>(g, transA, transB, vec, st, splits);
 }

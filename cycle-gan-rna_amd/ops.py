@@ -48,6 +48,16 @@ class HipOps:
         self.lib = _lib.load()
         self.device = torch.device(device if device is not None else "cuda:0")
         self._gemm_events = None
+        # scratch shared by the kernels that need one (split-K partials, BatchNorm chunk sums); kernels on
+        # one stream run in order, so one buffer per use serves every call
+        self._gemm_ws = torch.empty(8 << 20, dtype=torch.float32, device=self.device)      # 32 MiB
+        self._bn_ws = torch.empty(1 << 20, dtype=torch.float64, device=self.device)        # 8 MiB
+
+    def _bnws(self, M, N):
+        need = self.lib.cg_bn_workspace_bytes(M, N)
+        if need > self._bn_ws.numel() * 8:
+            self._bn_ws = torch.empty(need // 8 + 1, dtype=torch.float64, device=self.device)
+        return C.c_void_p(self._bn_ws.data_ptr()), self._bn_ws.numel() * 8
 
     # -- measurement: HIP events around every GEMM launch, on the launch stream ----------
     def begin_gemm_timing(self):
@@ -92,7 +102,7 @@ class HipOps:
             e0.record(torch.cuda.current_stream(self.device))
         st = self.lib.cg_gemm(_ptr(Cm), _ld(Cm), _ptr(A), _ld(A), _ptr(B), _ld(B), M, N, K, int(transA), int(transB),
                               0, _ptr(bias), epi, _ptr(E), _ld(E), _ptr(aux), _ld(aux), float(slope),
-                              int(accumulate), self._stream())
+                              int(accumulate), _ptr(self._gemm_ws), self._gemm_ws.numel() * 4, self._stream())
         if self._gemm_events is not None:
             e1.record(torch.cuda.current_stream(self.device))
             self._gemm_events.append((e0, e1, 2.0 * M * N * K))
@@ -105,7 +115,7 @@ class HipOps:
         assert Y.shape == X.shape and gamma.numel() == N and mean.numel() == N and invstd.numel() == N
         st = self.lib.cg_bn_fwd(_ptr(Y), _ld(Y), _ptr(X), _ld(X), M, N, _ptr(gamma), _ptr(beta), eps, _ptr(mean),
                                 _ptr(invstd), _ptr(rmean), _ptr(rvar), momentum, float(slope), _ptr(mask), _ld(mask),
-                                _ptr(pm), _ld(pm), None, 0, self._stream())
+                                _ptr(pm), _ld(pm), None, 0, *self._bnws(M, N), self._stream())
         _lib.check(st, "cg_bn_fwd")
 
     def bn_eval(self, Y, X, gamma, beta, rmean, rvar, slope, eps=1e-5):
@@ -119,7 +129,8 @@ class HipOps:
         assert dX.shape == X.shape and dY.shape == X.shape
         st = self.lib.cg_bn_bwd(_ptr(dX), _ld(dX), _ptr(dY), _ld(dY), _ptr(X), _ld(X), _ptr(Y), _ld(Y), _ptr(PM),
                                 _ld(PM), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(dgamma), _ptr(dbeta),
-                                int(accumulate), _ptr(gbar), _ptr(gxbar), float(slope), M, N, self._stream())
+                                int(accumulate), _ptr(gbar), _ptr(gxbar), float(slope), M, N, *self._bnws(M, N),
+                                self._stream())
         _lib.check(st, "cg_bn_bwd")
 
     def bn_bwd_bwd(self, Vu, Vh, dgamma, accumulate, W, U1, X, mean, invstd, gamma, ubar, mbar):
@@ -127,7 +138,7 @@ class HipOps:
         assert Vu.shape == X.shape and Vh.shape == X.shape and W.shape == X.shape and U1.shape == X.shape
         st = self.lib.cg_bn_bwd_bwd(_ptr(Vu), _ld(Vu), _ptr(Vh), _ld(Vh), _ptr(dgamma), int(accumulate), _ptr(W),
                                     _ld(W), _ptr(U1), _ld(U1), _ptr(X), _ld(X), _ptr(mean), _ptr(invstd), _ptr(gamma),
-                                    _ptr(ubar), _ptr(mbar), M, N, self._stream())
+                                    _ptr(ubar), _ptr(mbar), M, N, *self._bnws(M, N), self._stream())
         _lib.check(st, "cg_bn_bwd_bwd")
 
     # -- elementwise ------------------------------------------------------------

@@ -57,11 +57,14 @@ int cg_version(void);
  * 165,169,172,174; transA=0, transB=1), its input gradient (0,0), its weight
  * gradient (1,0), and the second-order products of the gradient penalty
  * (:194-204).  `accumulate` != 0 adds into C (CG_EPI_NONE only).
+ * workspace (may be NULL): scratch for split-K partial sums, used when the
+ * output has few tiles and K is long; any size is accepted (a larger one allows
+ * more splits), 16-byte aligned.
  */
 int cg_gemm(float* C, int ldc, const void* A, int lda, const void* B, int ldb,
             int M, int N, int K, int transA, int transB, int dtype,
             const float* bias, int epi, const float* E, int lde, float* aux, int ldaux,
-            float slope, int accumulate, void* stream);
+            float slope, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * Train-mode BatchNorm1d over the M rows of X (GAN_functions.py:60,63,89,93,
@@ -73,13 +76,16 @@ int cg_gemm(float* C, int ldc, const void* A, int lda, const void* B, int ldb,
  * for the backward; running_mean/running_var (may be NULL) are updated with
  * `momentum` and the unbiased variance; pm_out (may be NULL) receives pm.
  * Y may alias X.  ybf16 (may be NULL) receives Y rounded to bf16.
+ * workspace: cg_bn_workspace_bytes(M, N) bytes of scratch for the per-chunk
+ * column sums (the same rule holds for cg_bn_bwd and cg_bn_bwd_bwd).
  */
+size_t cg_bn_workspace_bytes(int M, int N);
 int cg_bn_fwd(float* Y, int ldy, const float* X, int ldx, int M, int N,
               const float* gamma, const float* beta, float eps,
               float* mean_out, float* invstd_out,
               float* running_mean, float* running_var, float momentum,
               float slope, const float* mask, int ldmask, float* pm_out, int ldpm,
-              void* ybf16, int ldybf16, void* stream);
+              void* ybf16, int ldybf16, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * Eval-mode BatchNorm1d + activation (g_m2h.eval() translation pass,
@@ -102,7 +108,8 @@ int cg_bn_bwd(float* dX, int lddx, const float* dY, int lddy, const float* X, in
               const float* Y, int ldy, const float* PM, int ldpm,
               const float* mean, const float* invstd, const float* gamma,
               float* dgamma, float* dbeta, int accumulate,
-              float* gbar_out, float* gxbar_out, float slope, int M, int N, void* stream);
+              float* gbar_out, float* gxbar_out, float slope, int M, int N,
+              void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * BatchNorm backward-of-backward for the gradient penalty
@@ -118,7 +125,8 @@ int cg_bn_bwd(float* dX, int lddx, const float* dY, int lddy, const float* X, in
 int cg_bn_bwd_bwd(float* V_u1, int ldvu, float* V_h0, int ldvh, float* dgamma, int accumulate,
                   const float* W, int ldw, const float* U1, int ldu, const float* X, int ldx,
                   const float* mean, const float* invstd, const float* gamma,
-                  const float* ubar, const float* mbar, int M, int N, void* stream);
+                  const float* ubar, const float* mbar, int M, int N,
+                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- elementwise / gather ------------------------------------------------ */
 
