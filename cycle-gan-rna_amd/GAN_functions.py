@@ -250,11 +250,17 @@ class _Backend:
         self.passes = {}
 
     def get_pass(self, b):
-        if b not in self.passes:
+        """Workspace for one module call.  A call that may be differentiated keeps
+        its workspace (the saved activations) to itself until its backward has
+        run; calls under no_grad share one per batch size."""
+        def make():
             if self.kind == "gen":
-                self.passes[b] = GenPass(self, self.net, self.in_dim, self.out_dim, b)
-            else:
-                self.passes[b] = DiscPass(self, self.net, self.in_dim, b)
+                return GenPass(self, self.net, self.in_dim, self.out_dim, b)
+            return DiscPass(self, self.net, self.in_dim, b)
+        if torch.is_grad_enabled():
+            return make()
+        if b not in self.passes:
+            self.passes[b] = make()
         return self.passes[b]
 
     def sync_counters(self):
@@ -265,8 +271,7 @@ class _Backend:
 
 class _GenFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, be, x, cat, *params):
-        p = be.get_pass(x.shape[0])
+    def forward(ctx, be, p, x, cat, *params):
         noise = be.noise(x.device)
         xc = x.detach().contiguous().float()
         out = p.forward(xc, cat, noise, train=be.module.training)
@@ -282,13 +287,12 @@ class _GenFn(torch.autograd.Function):
         if d_out is None:
             d_out = torch.zeros(p.b, p.out_dim, device=be.ops.device)
         dx = p.backward(f(d_out), need_dx=ctx.need_dx, d_mu=f(d_mu), d_lv=f(d_lv))
-        return (None, dx, None, *[be.net.G[k].clone() for k in be.keys])
+        return (None, None, dx, None, *[be.net.G[k].clone() for k in be.keys])
 
 
 class _DiscFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, be, x, cat, *params):
-        p = be.get_pass(x.shape[0])
+    def forward(ctx, be, p, x, cat, *params):
         noise = be.noise(x.device)
         xc = x.detach().contiguous().float()
         val, feat = p.forward(xc, cat, noise, train=be.module.training)
@@ -313,7 +317,7 @@ class _DiscFn(torch.autograd.Function):
         if d_feat is not None:
             ops.axpby(dfeat, 1.0, dfeat, 1.0, d_feat.contiguous().float())
         p.backward(None, dfeat=dfeat, param_grads=True, dx_out=dx)
-        return (None, dx, None, *[be.net.G[k].clone() for k in be.keys])
+        return (None, None, dx, None, *[be.net.G[k].clone() for k in be.keys])
 
 
 class GeneExpressionGenerator(nn.Module):
@@ -370,7 +374,7 @@ class GeneExpressionGenerator(nn.Module):
         if cat_covs is not None:
             cat_covs = cat_covs.to(x.device)
         params = [dict(self.named_parameters())[k] for k in be.keys]
-        return _GenFn.apply(be, x, cat_covs, *params)
+        return _GenFn.apply(be, be.get_pass(x.shape[0]), x, cat_covs, *params)
 
     def normalize_to_library_size(self, x):
         ops = _ops(x.device)
@@ -398,7 +402,7 @@ class GeneExpressionDiscriminator(nn.Module):
         if cat_covs is not None:
             cat_covs = cat_covs.to(x.device)
         params = [dict(self.named_parameters())[k] for k in be.keys]
-        out, feat = _DiscFn.apply(be, x, cat_covs, *params)
+        out, feat = _DiscFn.apply(be, be.get_pass(x.shape[0]), x, cat_covs, *params)
         return (out, feat) if return_features else out
 
 
@@ -407,10 +411,9 @@ class GeneExpressionDiscriminator(nn.Module):
 # --------------------------------------------------------------------------- #
 class _GPFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, be, real, fake, cat, *params):
+    def forward(ctx, be, p, real, fake, cat, *params):
         ops = be.ops
         b = real.shape[0]
-        p = be.get_pass(b)
         noise = be.noise(real.device)
         alpha = noise.rand((b, 1))
         xhat = torch.empty(b, real.shape[1], device=real.device)
@@ -439,7 +442,7 @@ class _GPFn(torch.autograd.Function):
         s = dgp.float()
         d_real = ctx.alpha * ctx.dxh * s if ctx.need[0] else None
         d_fake = (1 - ctx.alpha) * ctx.dxh * s if ctx.need[1] else None
-        return (None, d_real, d_fake, None, *[g * s for g in ctx.grads])
+        return (None, None, d_real, d_fake, None, *[g * s for g in ctx.grads])
 
 
 def compute_gradient_penalty(discriminator, real_samples, fake_samples, device, cat_covs=None):
@@ -451,7 +454,7 @@ def compute_gradient_penalty(discriminator, real_samples, fake_samples, device, 
     if cat_covs is not None:
         cat_covs = cat_covs.to(real_samples.device)
     params = [dict(discriminator.named_parameters())[k] for k in be.keys]
-    return _GPFn.apply(be, real_samples, fake_samples, cat_covs, *params)
+    return _GPFn.apply(be, be.get_pass(real_samples.shape[0]), real_samples, fake_samples, cat_covs, *params)
 
 
 def compute_cell_type_centroids(adata, tensor, device):

@@ -105,7 +105,7 @@ def module_level(R):
         w_out = torch.randn(B, gh, generator=gen)
         w_mu = torch.randn(B, 256, generator=gen)
         w_lv = torch.randn(B, 256, generator=gen)
-        fx = dict(torch_version=torch.__version__, cfg_preprocess_type=ptype, g_mouse=gm, g_human=gh, B=B,
+        fx = dict(torch_version=str(torch.__version__), cfg_preprocess_type=ptype, g_mouse=gm, g_human=gh, B=B,
                   init_seed=7, noise_seed=21, xm=xm, xh=xh, lm=lm, lh=lh, w_out=w_out, w_mu=w_mu, w_lv=w_lv)
 
         # ---- generator forward + backward (reference) ----
@@ -271,7 +271,7 @@ def function_level(R):
         ref, nets, data, metrics = run_reference_function(R, cfg, gm, gh, N, init_seed=3, data_seed=100, train_seed=9)
         tr, metrics2 = run_oracle_function(nets, cfg, data, train_seed=9)
         compare_function(tag, ref, tr, metrics, metrics2)
-        fx = dict(torch_version=torch.__version__, cfg={k: v for k, v in cfg.items() if k != 'device'},
+        fx = dict(torch_version=str(torch.__version__), cfg={k: v for k, v in cfg.items() if k != 'device'},
                   g_mouse=gm, g_human=gh, N=N, init_seed=3, data_seed=100, train_seed=9,
                   metrics={k: [float(v) for v in vals] for k, vals in metrics.items()},
                   final={name: {k: sample(v) for k, v in m.state_dict().items()}
@@ -287,7 +287,7 @@ def trajectory_level(R):
     ref, nets, data, metrics = run_reference_function(R, cfg, 2000, 2000, 512, init_seed=0, data_seed=1234, train_seed=1)
     tr, metrics2 = run_oracle_function(nets, cfg, data, train_seed=1)
     compare_function("traj", ref, tr, metrics, metrics2)
-    fx = dict(torch_version=torch.__version__, cfg={k: v for k, v in cfg.items() if k != 'device'},
+    fx = dict(torch_version=str(torch.__version__), cfg={k: v for k, v in cfg.items() if k != 'device'},
               g_mouse=2000, g_human=2000, N=512, init_seed=0, data_seed=1234, train_seed=1,
               metrics={k: [float(v) for v in vals] for k, vals in metrics.items()},
               # the float32 oracle on the same seeds: the gap between two CPU float32

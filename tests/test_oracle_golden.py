@@ -1,0 +1,149 @@
+"""The CPU oracle against the golden vectors captured from the imported
+reference (oracle/make_golden.py), plus the small host-side pieces.
+
+These run without a GPU.  They pin oracle/cyclegan_oracle.py - the checker used
+on the GPU box - to the reference's own outputs: module level with the recorded
+noise replayed, function level through the loop scaffolding, and the first
+epochs of the BASELINE configuration-1 trajectory.
+"""
+import os
+
+import pytest
+import torch
+
+from oracle import cyclegan_oracle as O
+from oracle import init_params
+from oracle.train_loop import ShuffledBatches, oracle_train
+from tests.helpers import rel
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return torch.load(os.path.join(GOLD, name), weights_only=True)
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_module_level(tag):
+    fx = load("module_level.pt")[tag]
+    cfg = O.default_config(hidden_dims=[96, 64, 32], preprocess_type=fx["cfg_preprocess_type"])
+    nets = init_params.build_nets(fx["g_mouse"], fx["g_human"], [12], cfg, fx["init_seed"])
+    xm, lm, lh = fx["xm"], fx["lm"], fx["lh"]
+    g = fx["gen"]
+    P = {k: v.clone() for k, v in nets["g_m2h"].items()}
+    for k in O.param_names(P):
+        P[k].requires_grad_(True)
+    out, mu, lv = O.generator_forward(P, xm, lm, cfg, O.RecordedNoise(g["noise"]), train=True)
+    assert rel(out, g["out"]) <= 1e-4 and rel(mu, g["mu"]) <= 1e-4 and rel(lv, g["log_var"]) <= 1e-4
+    ((out * fx["w_out"]).sum() + (mu * fx["w_mu"]).sum() + (lv * fx["w_lv"]).sum()).backward()
+    floor = 1e-3 * max(float(v.abs().max()) for v in g["grads"].values())
+    for k, ref in g["grads"].items():
+        assert rel(P[k].grad, ref, floor) <= 0.5, k            # i.e. 5e-4 of the largest gradient
+    for k, ref in g["buffers"].items():
+        assert rel(P[k].double(), ref.double()) <= 1e-4, k
+    ge = fx["gen_eval"]
+    with torch.no_grad():
+        oe, _, _ = O.generator_forward({k: v.clone() for k, v in ge["state"].items()}, xm, lm, cfg,
+                                       O.RecordedNoise(ge["noise"]), train=False)
+    assert rel(oe, ge["out"]) <= 1e-4
+    d = fx["disc"]
+    Pd = {k: v.clone() for k, v in nets["d_m"].items()}
+    for k in O.param_names(Pd):
+        Pd[k].requires_grad_(True)
+    nz = O.RecordedNoise(d["noise"])
+    fake = d["fake"].clone().requires_grad_(True)
+    val, feat = O.discriminator_forward(Pd, xm, lm, nz)
+    val_f, _ = O.discriminator_forward(Pd, fake.detach(), lh, nz)
+    gp = O.gradient_penalty(Pd, xm, fake, lh, nz)
+    assert rel(val, d["validity"]) <= 1e-4 and rel(feat, d["features"]) <= 1e-4 and rel(gp, d["gp"]) <= 1e-4
+    (-val.mean() + val_f.mean() + 13 * gp).backward()
+    assert rel(fake.grad, d["grad_fake"], 1e-3 * float(d["grad_fake"].abs().max())) <= 0.5
+    floor = 1e-3 * max(float(s["values"].abs().max()) for s in d["grads"].values())
+    for k, spec in d["grads"].items():
+        got = Pd[k].grad.reshape(-1).double()[::spec["stride"]].float()
+        assert rel(got, spec["values"], floor) <= 0.5, k
+
+
+@pytest.mark.parametrize("tag", ["one_iter_epochs", "cadence_linear"])
+def test_function_level(tag):
+    fx = load("function_level.pt")[tag]
+    cfg = dict(fx["cfg"])
+    gm, gh, N = fx["g_mouse"], fx["g_human"], fx["N"]
+    nets = init_params.build_nets(gm, gh, [12], cfg, fx["init_seed"])
+    xm, _ = O.synthetic_expression(N, gm, 12, seed=fx["data_seed"])
+    xh, _ = O.synthetic_expression(N, gh, 12, seed=fx["data_seed"] + 1)
+    lm, lh = O.balanced_labels(N, 12, fx["data_seed"] + 2), O.balanced_labels(N, 12, fx["data_seed"] + 3)
+    tr = O.OracleTrainer(nets, cfg, O.centroid_table(xm, lm, 12), O.centroid_table(xh, lh, 12))
+    torch.manual_seed(fx["train_seed"])
+    metrics = oracle_train(tr, xm, xh, lm[:, None], lh[:, None], cfg)
+    for k, ref in fx["metrics"].items():
+        for ep, (a, b) in enumerate(zip(metrics[k], ref)):
+            assert rel(a, b, 0.5 if k.endswith("_loss") and k[0] in "gd" else 0.0) <= (1e-4 if ep == 0 else 5e-3), (k, ep, a, b)
+
+
+def test_trajectory_cfg1_first_epochs_and_noise_floor():
+    """BASELINE configuration 1 (G=2000, B=128, default architecture): the
+    oracle reproduces the reference's first epoch (4 iterations) to 1e-4 and the second to 2e-2,
+    and the recorded 100-iteration run documents how far two float32 CPU
+    implementations drift apart (the floor for any device comparison)."""
+    fx = load("trajectory_cfg1.pt")
+    cfg = dict(fx["cfg"], epochs=2)
+    nets = init_params.build_nets(2000, 2000, [12], cfg, fx["init_seed"])
+    xm, _ = O.synthetic_expression(fx["N"], 2000, 12, seed=fx["data_seed"])
+    xh, _ = O.synthetic_expression(fx["N"], 2000, 12, seed=fx["data_seed"] + 1)
+    lm, lh = O.balanced_labels(fx["N"], 12, fx["data_seed"] + 2), O.balanced_labels(fx["N"], 12, fx["data_seed"] + 3)
+    tr = O.OracleTrainer(nets, cfg, O.centroid_table(xm, lm, 12), O.centroid_table(xh, lh, 12))
+    torch.manual_seed(fx["train_seed"])
+    torch.set_num_threads(8)
+    metrics = oracle_train(tr, xm, xh, lm[:, None], lh[:, None], cfg)
+    for k in ("g_loss", "d_m_loss", "d_h_loss", "cycle_loss", "celltype_loss", "kl_loss"):
+        assert rel(metrics[k][0], fx["metrics"][k][0], 0.5) <= 1e-4, (k, metrics[k][0], fx["metrics"][k][0])
+        assert rel(metrics[k][1], fx["metrics"][k][1], 0.5) <= 2e-2, (k, metrics[k][1], fx["metrics"][k][1])
+    drift = max(rel(fx["oracle_metrics"][k][-1], fx["metrics"][k][-1], 0.5) for k in ("cycle_loss", "celltype_loss", "kl_loss"))
+    assert drift < 0.1     # 25 epochs in, same order of magnitude, no longer 1e-4
+
+
+def test_shuffled_batches_equal_dataloader():
+    """The scaffolding's stand-in for DataLoader(shuffle=True) yields the same
+    batches and consumes the global generator identically."""
+    from torch.utils.data import DataLoader, TensorDataset
+    x, y = torch.arange(23.).reshape(23, 1) * torch.ones(1, 3), torch.arange(23)[:, None]
+    torch.manual_seed(4)
+    ref = []
+    dl = DataLoader(TensorDataset(x, y), batch_size=5, shuffle=True)
+    for _ in range(2):
+        ref += [(a.clone(), b.clone()) for a, b in dl]
+    tail_ref = torch.rand(1)
+    torch.manual_seed(4)
+    got = []
+    sb = ShuffledBatches(x, y, 5)
+    assert len(sb) == len(dl)
+    for _ in range(2):
+        it = iter(sb)
+        while True:
+            try:
+                got.append(next(it))
+            except StopIteration:
+                break
+    assert len(got) == len(ref) and all(torch.equal(a, c) and torch.equal(b, d) for (a, b), (c, d) in zip(got, ref))
+    assert torch.equal(torch.rand(1), tail_ref)
+
+
+def test_lr_schedule_quirks():
+    """GAN_functions.py:236-247: unchanged before decay_start_epoch; cosine jumps to lr*decay_factor at progress 0."""
+    assert O.lr_decay(2e-4, 3, 5, 10, 0.1, "cosine") == (2e-4, None)
+    v, new = O.lr_decay(2e-4, 5, 5, 10, 0.1, "cosine")
+    assert abs(v - 2e-5) < 1e-12 and new == v
+    v, _ = O.lr_decay(2e-4, 7, 5, 10, 0.1, "linear")
+    assert abs(v - 2e-4 * (1 - 0.4 * 0.1)) < 1e-12
+
+
+def test_gauge_parameter_classification():
+    cfg = O.default_config(hidden_dims=[96, 64, 32])
+    sd = init_params.generator_state(40, 40, [12], cfg)
+    gauge = {k for k in sd if O.is_gauge_param(k, sd)}
+    assert "encoder.0.bias" in gauge and "decoder.6.bias" in gauge and "residual_attention_blocks.2.0.block.3.bias" in gauge
+    assert "residual_attention_blocks.3.1.norm.bias" in gauge and "residual_attention_blocks.0.1.norm.bias" not in gauge
+    assert "decoder.9.bias" not in gauge and "mu.bias" not in gauge and "encoder.1.bias" not in gauge
+    dd = init_params.discriminator_state(40, [12])
+    assert {k for k in dd if O.is_gauge_param(k, dd)} == {"model.0.bias"}
