@@ -96,7 +96,10 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
   constexpr int B_ELEMS = B_MMAJ ? BK * (BN + 4) : BN * (BK + 4);
   __shared__ __align__(16) float smem[2 * (A_ELEMS + B_ELEMS)];
 
-  const int tile = blockIdx.x;
+  // Workgroups are dealt round-robin over the 8 XCDs; give each XCD a contiguous run of tiles (neighbours share
+  // an A row panel and adjacent B panels) so that panel re-reads hit that XCD's L2.  Bijective for any grid size.
+  const int nwg = gridDim.x, q = nwg >> 3, rem = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
   const int bm = (tile / g.tiles_n) * BM, bn = (tile % g.tiles_n) * BN;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
@@ -215,16 +218,24 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
     }
 }
 
-// C = (accumulate ? C : 0) + bias + sum over splits of the partials, in split order.
-__global__ void __launch_bounds__(256) splitk_reduce_kernel(float* C, int ldc, const float* ws, int splits, int M,
-                                                            int N, const float* bias, int accumulate) {
-  const size_t total = (size_t)M * N;
+// Combine the split-K partials in split order and apply the epilogue of cg_gemm.
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(GemmArgs g, int splits) {
+  const size_t total = (size_t)g.M * g.N;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int m = (int)(i / N), n = (int)(i % N);
-    float s = bias ? bias[n] : 0.f;
-    for (int k = 0; k < splits; ++k) s += ws[(size_t)k * total + i];
-    float* cp = C + (size_t)m * ldc + n;
-    *cp = accumulate ? *cp + s : s;
+    const int m = (int)(i / g.N), n = (int)(i % g.N);
+    float h = g.bias ? g.bias[n] : 0.f;
+    for (int k = 0; k < splits; ++k) h += g.ws[(size_t)k * total + i];
+    float* cp = g.C + (size_t)m * g.ldc + n;
+    if (g.epi == CG_EPI_NONE) {
+      *cp = g.accumulate ? *cp + h : h;
+    } else if (g.epi == CG_EPI_LEAKY) {
+      float pm = h > 0.f ? 1.f : g.slope;
+      if (g.E) pm *= g.E[(size_t)m * g.lde + n];
+      *cp = h * pm;
+      if (g.aux) g.aux[(size_t)m * g.ldaux + n] = pm;
+    } else {
+      *cp = h * g.E[(size_t)m * g.lde + n];
+    }
   }
 }
 
@@ -253,8 +264,7 @@ int launch_f32(const GemmArgs& g, int transA, int transB, bool vec, hipStream_t 
     const size_t total = (size_t)g.M * g.N;
     int blocks = (int)((total + 255) / 256);
     if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, g.C, g.ldc, g.ws, splits, g.M, g.N,
-                       g.bias, g.accumulate);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, g, splits);
   }
   return cg_launch_status();
 }
@@ -281,23 +291,33 @@ extern "C" int cg_gemm(float* C, int ldc, const void* A, int lda, const void* B,
   GemmArgs g{(const float*)A, (const float*)B, C, bias, E, aux, M, N, K, lda, ldb, ldc, lde, ldaux,
              epi, accumulate, slope, 0, 1 << 30, (float*)workspace};
   const bool vec = (((uintptr_t)A | (uintptr_t)B) % 16 == 0) && (lda % 4 == 0) && (ldb % 4 == 0);
-  // Tile choice: the largest tile that still yields about one block per CU.
-  const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128);
-  const long t12864 = (long)((M + 127) / 128) * ((N + 63) / 64);
-  if (t128 >= 192) return launch_f32<128, 128>(g, transA, transB, vec, st);
-  if (t12864 >= 192) return launch_f32<128, 64>(g, transA, transB, vec, st);
-  // Few output tiles and a long reduction (weight gradients of the 16x16 token layers: K = 16*batch;
-  // 512-row layers with 512 or 1024 outputs): split K over blockIdx.y so the chip is filled.
-  int splits = 1;
-  const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64);
+  // Tile and split-K choice by a small cost model: a K slab of a tile costs max(MFMA cycles, staged bytes at
+  // ~10 B/clk/CU); the launch takes ceil(blocks / 256 CUs) rounds of (slabs per split) such slabs, plus the slab
+  // round trip of the partial sums when K is split.  Large tiles stage fewer bytes per FLOP, splits fill the chip.
   const int nk = (K + BK - 1) / BK;
-  if (epi == CG_EPI_NONE && workspace && t64 <= 96 && nk >= 8) {
-    splits = (int)(256 / t64);
-    if (splits > nk / 4) splits = nk / 4;
-    if (splits > 64) splits = 64;
-    const size_t per = (size_t)M * N * sizeof(float);
-    if ((size_t)splits * per > workspace_bytes) splits = (int)(workspace_bytes / per);
-    if (splits < 2) splits = 1;
+  const size_t per = (size_t)M * N * sizeof(float);
+  struct Cand { int bm, bn; double slab; } cands[3] = {{128, 128, 4096.0}, {128, 64, 2458.0}, {64, 64, 1638.0}};
+  int best = 2, best_splits = 1;
+  double best_cost = 1e300;
+  for (int c = 0; c < 3; ++c) {
+    const long tiles = (long)((M + cands[c].bm - 1) / cands[c].bm) * ((N + cands[c].bn - 1) / cands[c].bn);
+    int smax = 1;
+    if (workspace && nk >= 16) {
+      smax = nk / 8;
+      if (smax > 32) smax = 32;
+      if ((size_t)smax * per > workspace_bytes) smax = (int)(workspace_bytes / per);
+      if (smax < 1) smax = 1;
+    }
+    for (int sp = 1; sp <= smax; sp = sp < 4 ? sp + 1 : sp * 2) {
+      const long blocks = tiles * sp;
+      const long rounds = (blocks + 255) / 256;
+      const int slabs = (nk + sp - 1) / sp;
+      double cost = (double)rounds * (slabs * cands[c].slab + 3000.0);
+      if (sp > 1) cost += 2.0 * sp * (double)per / (256.0 * 10.0) + 4000.0;
+      if (cost < best_cost) { best_cost = cost; best = c; best_splits = sp; }
+    }
   }
-  return launch_f32<64, 64>(g, transA, transB, vec, st, splits);
+  if (best == 0) return launch_f32<128, 128>(g, transA, transB, vec, st, best_splits);
+  if (best == 1) return launch_f32<128, 64>(g, transA, transB, vec, st, best_splits);
+  return launch_f32<64, 64>(g, transA, transB, vec, st, best_splits);
 }
