@@ -539,6 +539,8 @@ class StepEngine:
         self.var_out = Z(2)
         self.var_ws = Z(max((max(gm, gh) + 31) // 32, 1), dtype=torch.float64)
         self._d_scales_b = None
+        self._pin = None
+        self.use_graphs = False
         from .ddp import GradSync
         self.sync = GradSync(ops.device)
         self.g_tot = Z(10, dtype=torch.float64)
@@ -551,16 +553,72 @@ class StepEngine:
         self.lr_g = lr
         self.lr_d = lr
 
-    def _adam(self, arena, lr):
+    def _begin_opt(self, arena, lr):
+        """Host side of an optimizer step: advance the step count and upload {lr, step}
+        (the Adam kernel reads them from device memory, so a captured step can be replayed)."""
         arena.step += 1
-        arena.lr_step.copy_(torch.tensor([lr, float(arena.step)], dtype=torch.float64))
+        if self._pin is None:
+            pin = self.ops.device.type == "cuda"
+            self._pin = {id(self.arena_d): torch.zeros(2, dtype=torch.float64, pin_memory=pin),
+                         id(self.arena_g): torch.zeros(2, dtype=torch.float64, pin_memory=pin)}
+        host = self._pin[id(arena)]
+        host[0], host[1] = lr, float(arena.step)
+        arena.lr_step.copy_(host, non_blocking=True)
+
+    def _adam(self, arena):
         self.ops.adam(arena.p, arena.g, arena.m, arena.v, arena.vmax, arena.lr_step, 0.5, 0.9, 1e-8)
+
+    # ---- HIP graphs ------------------------------------------------------------------
+    def enable_graphs(self):
+        """Capture the device work of the critic step and of the generator step into HIP
+        graphs (first full-size call runs eagerly, the second is captured, later ones are
+        replayed).  Needs a noise source that draws into fixed device buffers
+        (noise.DeviceNoise); ragged batches and multi-rank runs stay eager."""
+        self._graphs = {}
+        self.use_graphs = True
+
+    def _graphed(self, kind, body, tensors, noise):
+        st = self._graphs.setdefault(kind, dict(calls=0, graph=None, static=None, nbt=None))
+        if st["static"] is None:
+            st["static"] = [torch.empty_like(t) for t in tensors]
+        for dst, src in zip(st["static"], tensors):
+            dst.copy_(src)
+        st["calls"] += 1
+        if st["calls"] == 1:
+            body(*st["static"], noise)
+            return
+        if st["graph"] is None:
+            before = {n: dict(net.nbt) for n, net in self.nets.items()}
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                body(*st["static"], noise)
+            st["graph"] = g
+            st["nbt"] = {n: {k: net.nbt[k] - before[n][k] for k in net.nbt} for n, net in self.nets.items()}
+            g.replay()
+            return
+        st["graph"].replay()
+        for n, d in st["nbt"].items():
+            for k, v in d.items():
+                if v:
+                    self.nets[n].nbt[k] += v
 
     # ---- critic step (:322-340) -------------------------------------------------------
     def d_step(self, mouse, human, mouse_cat, human_cat, noise):
-        ops, cfg = self.ops, self.cfg
         b = mouse.shape[0]
         assert human.shape[0] == b and b <= self.max_b
+        self._begin_opt(self.arena_d, self.lr_d)
+        if self._d_scales_b != b:
+            lam = float(self.cfg["lambda_gp"])
+            self.d_scales.copy_(torch.tensor([-1.0 / b, 1.0 / b, lam / b] * 2, dtype=torch.float64))
+            self._d_scales_b = b
+        if self.use_graphs and b == self.max_b and not self.sync.enabled:
+            self._graphed("d", self._d_body, (mouse, human, mouse_cat, human_cat), noise)
+        else:
+            self._d_body(mouse, human, mouse_cat, human_cat, noise)
+
+    def _d_body(self, mouse, human, mouse_cat, human_cat, noise):
+        ops, cfg = self.ops, self.cfg
+        b = mouse.shape[0]
         self.arena_d.g.zero_()
         fake_human = self.gen_a["g_m2h"].forward(mouse, mouse_cat, noise)
         fake_mouse = self.gen_a["g_h2m"].forward(human, human_cat, noise)
@@ -581,11 +639,7 @@ class StepEngine:
             dp.gp_backward(cfg["lambda_gp"], self.red, s0 + 2)
             self.sync.launch(self.arena_d.net_grad(name))
         self.sync.wait()
-        self._adam(self.arena_d, self.lr_d)
-        if self._d_scales_b != b:
-            lam = float(cfg["lambda_gp"])
-            self.d_scales.copy_(torch.tensor([-1.0 / b, 1.0 / b, lam / b] * 2, dtype=torch.float64))
-            self._d_scales_b = b
+        self._adam(self.arena_d)
         ops.sum_parts(self.d_tot, self.red, self.d_slots, self.d_scales)
 
     def d_losses(self):
@@ -597,6 +651,14 @@ class StepEngine:
 
     # ---- generator step (:343-419) -------------------------------------------------------
     def g_step(self, mouse, human, mouse_cat, human_cat, noise):
+        b = mouse.shape[0]
+        self._begin_opt(self.arena_g, self.lr_g)
+        if self.use_graphs and b == self.max_b and not self.sync.enabled:
+            self._graphed("g", self._g_body, (mouse, human, mouse_cat, human_cat), noise)
+        else:
+            self._g_body(mouse, human, mouse_cat, human_cat, noise)
+
+    def _g_body(self, mouse, human, mouse_cat, human_cat, noise):
         ops, cfg = self.ops, self.cfg
         b = mouse.shape[0]
         gm, gh = self.g_mouse, self.g_human
@@ -672,7 +734,7 @@ class StepEngine:
         Bp.backward(dfm, kl=(coef, 4, 1.0))
         self.sync.launch(self.arena_g.net_grad("g_h2m"))
         self.sync.wait()
-        self._adam(self.arena_g, self.lr_g)
+        self._adam(self.arena_g)
         ops.colvar_mean(self.var_out[0:1], self.var_ws, fake_human)        # :418-419
         ops.colvar_mean(self.var_out[1:2], self.var_ws, fake_mouse)
         self.fake_human, self.fake_mouse = fake_human, fake_mouse

@@ -58,10 +58,17 @@ class DeviceNoise:
     """Draws straight into HBM.  Buffers are reused per (kind, shape, call index
     within a step) so that a captured step replays with fresh numbers."""
 
-    def __init__(self, device, seed=0):
+    def __init__(self, device, seed=0, default_generator=False):
+        """default_generator=True draws from torch's default CUDA generator (seeded
+        here), which HIP-graph capture supports; otherwise a private generator is used."""
         self.device = torch.device(device)
-        self.gen = torch.Generator(device=self.device)
-        self.gen.manual_seed(seed)
+        if default_generator:
+            self.gen = None
+            with torch.cuda.device(self.device):
+                torch.cuda.manual_seed(seed)
+        else:
+            self.gen = torch.Generator(device=self.device)
+            self.gen.manual_seed(seed)
         self.bufs = {}
         self.count = {}
 

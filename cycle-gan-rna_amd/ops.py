@@ -108,6 +108,14 @@ class HipOps:
             self._gemm_events.append((e0, e1, 2.0 * M * N * K))
         _lib.check(st, "cg_gemm")
 
+    def gemm_untimed(self, *args, **kw):
+        """gemm() without event bracketing even while begin_gemm_timing() is active."""
+        ev, self._gemm_events = self._gemm_events, None
+        try:
+            self.gemm(*args, **kw)
+        finally:
+            self._gemm_events = ev
+
     # -- BatchNorm --------------------------------------------------------------
     def bn_fwd(self, Y, X, gamma, beta, mean, invstd, rmean, rvar, slope, mask=None, pm=None, eps=1e-5,
                momentum=0.1):

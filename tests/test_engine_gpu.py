@@ -139,3 +139,29 @@ def test_ragged_batch_smaller_than_workspace(ops):
     g = eng.iteration(0, xm[:b].cuda(), xh[:b].cuda(), lm[:b, None].cuda(), lh[:b, None].cuda(), HostReplayNoise(ops.device))
     for k in LOSS_KEYS:
         assert rel(g[k], e[k], FLOOR.get(k, 0.0)) <= 1e-4, (k, g[k], e[k])
+
+
+def test_graph_replay_equals_eager(ops):
+    """The captured critic/generator steps replay to the same parameters as launching every kernel from the host
+    (same device noise stream: torch's default generator advances identically under replay)."""
+    from cycle_gan_rna_amd.engine import StepEngine
+    from cycle_gan_rna_amd.noise import DeviceNoise
+    cfg = small_cfg(preprocess_type="log_normalized", nb_critic=2)
+    nets, xm, xh, lm, lh = make_problem(64, 64, 32, cfg)
+    cm, ch = O.centroid_table(xm, lm, 12), O.centroid_table(xh, lh, 12)
+    dx = [t.cuda() for t in (xm, xh, lm[:, None], lh[:, None])]
+    finals = []
+    for graphs in (False, True):
+        eng = StepEngine(nets, cfg, cm, ch, ops, 32)
+        if graphs:
+            eng.enable_graphs()
+        noise = DeviceNoise(ops.device, seed=7, default_generator=True)
+        for i in range(7):          # generator steps at i = 0, 2, 4, 6
+            noise.begin_step()
+            out = eng.iteration(i, *dx, noise)
+        torch.cuda.synchronize()
+        finals.append((eng.arena_d.p.clone(), eng.arena_g.p.clone(), out, dict(eng.nets["d_m"].nbt)))
+    (d0, g0, o0, n0), (d1, g1, o1, n1) = finals
+    assert n0 == n1
+    assert torch.equal(d0, d1) and torch.equal(g0, g1)
+    assert o0["g_loss"] == o1["g_loss"] and o0["d_m_loss"] == o1["d_m_loss"]
