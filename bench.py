@@ -31,6 +31,7 @@ BATCH = 512
 N_TYPES = 12
 NB_CRITIC = 4
 F32_MFMA_PEAK_TFLOPS = 157.3      # dense float32 matrix peak of MI355X
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 matrix peak
 
 
 def algorithmic_gflop_per_cell_iteration(G, nb_critic=4, E=12):
@@ -84,6 +85,8 @@ def main():
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32: exact float32 MFMA everywhere; bf16: large dense-layer products on the bf16 MFMA")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying HIP graphs")
     a = ap.parse_args()
 
@@ -109,7 +112,7 @@ def main():
     xm, lm = O.synthetic_expression(n_cells, G, N_TYPES, seed=1234 + 2 * rank)
     xh, lh = O.synthetic_expression(n_cells, G, N_TYPES, seed=1235 + 2 * rank)
     cm, ch = O.centroid_table(xm, lm, N_TYPES), O.centroid_table(xh, lh, N_TYPES)
-    ops = HipOps(dev)
+    ops = HipOps(dev, precision="bf16" if a.dtype == "bf16" else "fp32")
     eng = StepEngine(nets, cfg, cm, ch, ops, B)
     xm, xh, lm, lh = xm.to(dev), xh.to(dev), lm[:, None].to(dev), lh[:, None].to(dev)
     noise = DeviceNoise(dev, seed=1 + rank, default_generator=True)
@@ -164,9 +167,12 @@ def main():
         n_launch, gemm_ms, exec_flop = ops.end_gemm_timing()
         alg_flop = algorithmic_gflop_per_cell_iteration(G) * 1e9 * B * NB_CRITIC
         achieved = alg_flop / (gemm_ms * 1e-3) / 1e12
-        roof = dict(bound="mfma", achieved=achieved, peak=F32_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=achieved / F32_MFMA_PEAK_TFLOPS, traffic=None,
-                    kernel="gemm_f32_kernel (v_mfma_f32_32x32x2_f32)", launches_per_iteration=n_launch / NB_CRITIC,
+        peak = BF16_MFMA_PEAK_TFLOPS if a.dtype == "bf16" else F32_MFMA_PEAK_TFLOPS
+        kname = ("gemm_bf16_kernel (v_mfma_f32_16x16x32_bf16) + gemm_f32_kernel for the small products"
+                 if a.dtype == "bf16" else "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)")
+        roof = dict(bound="mfma", achieved=achieved, peak=peak, unit="TFLOP/s",
+                    frac=achieved / peak, traffic=None,
+                    kernel=kname, launches_per_iteration=n_launch / NB_CRITIC,
                     avg_launch_us=gemm_ms * 1e3 / n_launch, gemm_ms_per_iteration=gemm_ms / NB_CRITIC,
                     executed_tflops=exec_flop / (gemm_ms * 1e-3) / 1e12)
     if world > 1:
@@ -178,10 +184,10 @@ def main():
         line = {
             "metric": "train cells/sec (G+D fwd/bwd/update)", "value": B * world * a.steps / dt, "unit": "cells/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": f"CycleGAN MLP, {G} genes per species, batch {B} per GPU, nb_critic {NB_CRITIC}, "
                                    f"hidden 2048/1024/512, latent 256, {N_TYPES} cell types, log-normalised synthetic "
-                                   f"expression, float32 MFMA", "global_batch": B * world,
+                                   f"expression, {'bf16 MFMA for the large layers' if a.dtype == 'bf16' else 'float32 MFMA'}", "global_batch": B * world,
                        "parallelism": f"dp{world}"},
             "roofline": roof, "cpu_baseline": cpu,
         }

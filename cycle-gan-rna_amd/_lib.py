@@ -47,13 +47,13 @@ SIGNATURES = {
     "cg_gp_penalty": ([P, I, P, P, I, F, I, I, P], I),
     "cg_reduce_sum": ([P, P, P, I, I, I, P], I),
     "cg_reduce_l1": ([P, P, P, I, P, I, I, I, P], I),
-    "cg_reduce_centroid_sq": ([P, P, P, I, P, I, P, I, I, I, P], I),
+    "cg_reduce_centroid_sq": ([P, P, P, I, P, I, P, I, I, I, I, P], I),
     "cg_reduce_kl": ([P, P, P, I, I, I, P], I),
     "cg_colsum": ([P, P, I, I, I, F, I, P], I),
     "cg_reduce_sqdiff": ([P, P, P, I, P, I, I, I, P], I),
     "cg_colvar_mean": ([P, P, P, I, I, I, P], I),
     "cg_l1_bwd": ([P, I, P, I, P, I, P, I, F, I, I, I, P], I),
-    "cg_centroid_bwd": ([P, I, P, I, P, I, P, I, P, I, F, I, I, I, P], I),
+    "cg_centroid_bwd": ([P, I, P, I, P, I, P, I, P, I, F, I, I, I, I, P], I),
     "cg_fm_bwd": ([P, I, P, P, P, I, F, I, I, I, P], I),
     "cg_gloss_finalize": ([P, P, P, P, P, C.POINTER(GlossDesc), P], I),
     "cg_sum_parts": ([P, P, P, P, P, I, P], I),

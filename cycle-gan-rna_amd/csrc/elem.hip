@@ -182,12 +182,16 @@ __global__ void __launch_bounds__(256) reduce_l1_kernel(float* parts, int* npart
   write_part(s, parts, nparts);
 }
 
+__device__ __forceinline__ int64_t clamp_label(int64_t t, int n_types) {
+  return t < 0 ? 0 : (t >= n_types ? n_types - 1 : t);
+}
+
 __global__ void __launch_bounds__(256) reduce_centroid_kernel(float* parts, int* nparts, const float* A, int lda,
                                                               const float* Cn, int ldc, const int64_t* labels,
-                                                              int lstride, int M, int N) {
+                                                              int lstride, int M, int N, int n_types) {
   float s = 0.f;
   CG_2D_LOOP(M, N) {
-    const float d = A[(size_t)m * lda + col] - Cn[(size_t)labels[(size_t)m * lstride] * ldc + col];
+    const float d = A[(size_t)m * lda + col] - Cn[(size_t)clamp_label(labels[(size_t)m * lstride], n_types) * ldc + col];
     s += d * d;
   }
   write_part(s, parts, nparts);
@@ -282,10 +286,10 @@ __global__ void l1_bwd_kernel(float* dA, int ldd, const float* A, int lda, const
 
 __global__ void centroid_bwd_kernel(float* dA, int ldd, const float* A, int lda, const float* Cn, int ldc,
                                     const int64_t* labels, int lstride, const float* coef, int idx, float scale, int M,
-                                    int N, int accumulate) {
+                                    int N, int n_types, int accumulate) {
   const float k = coef[idx] * scale;
   CG_2D_LOOP(M, N) {
-    const float g = k * (A[(size_t)m * lda + col] - Cn[(size_t)labels[(size_t)m * lstride] * ldc + col]);
+    const float g = k * (A[(size_t)m * lda + col] - Cn[(size_t)clamp_label(labels[(size_t)m * lstride], n_types) * ldc + col]);
     float* o = dA + (size_t)m * ldd + col;
     *o = accumulate ? *o + g : g;
   }
@@ -466,12 +470,12 @@ extern "C" int cg_reduce_l1(float* parts, int* nparts, const float* A, int lda, 
 }
 
 extern "C" int cg_reduce_centroid_sq(float* parts, int* nparts, const float* A, int lda, const float* Cn, int ldc,
-                                     const int64_t* labels, int lstride, int M, int N, void* stream) {
-  if (!parts || !nparts || !A || !Cn || !labels || M <= 0 || N <= 0 || lda < N || ldc < N || lstride < 1)
+                                     const int64_t* labels, int lstride, int M, int N, int n_types, void* stream) {
+  if (!parts || !nparts || !A || !Cn || !labels || M <= 0 || N <= 0 || lda < N || ldc < N || lstride < 1 || n_types < 1)
     return CG_ERR_BAD_ARG;
   Grid2 g = grid_red(M, N);
   hipLaunchKernelGGL(reduce_centroid_kernel, g.grid, g.block, 0, ST, parts, nparts, A, lda, Cn, ldc, labels, lstride, M,
-                     N);
+                     N, n_types);
   return cg_launch_status();
 }
 
@@ -516,11 +520,12 @@ extern "C" int cg_l1_bwd(float* dA, int ldd, const float* A, int lda, const floa
 
 extern "C" int cg_centroid_bwd(float* dA, int ldd, const float* A, int lda, const float* Cn, int ldc,
                                const int64_t* labels, int lstride, const float* coef, int idx, float scale, int M,
-                               int N, int accumulate, void* stream) {
-  if (!dA || !A || !Cn || !labels || !coef || M <= 0 || N <= 0 || ldd < N || lda < N || ldc < N) return CG_ERR_BAD_ARG;
+                               int N, int n_types, int accumulate, void* stream) {
+  if (!dA || !A || !Cn || !labels || !coef || M <= 0 || N <= 0 || ldd < N || lda < N || ldc < N || n_types < 1)
+    return CG_ERR_BAD_ARG;
   Grid2 g = grid2(M, N);
   hipLaunchKernelGGL(centroid_bwd_kernel, g.grid, g.block, 0, ST, dA, ldd, A, lda, Cn, ldc, labels, lstride, coef, idx,
-                     scale, M, N, accumulate);
+                     scale, M, N, n_types, accumulate);
   return cg_launch_status();
 }
 

@@ -88,6 +88,180 @@ struct Stager {
   }
 };
 
+// One output element through the epilogue (bias already added by the caller where it applies).
+__device__ __forceinline__ void epilogue_store(const GemmArgs& g, int row, int col, float h) {
+  float* cp = g.C + (size_t)row * g.ldc + col;
+  if (g.epi == CG_EPI_NONE) {
+    if (g.accumulate) h += *cp;
+    *cp = h;
+  } else if (g.epi == CG_EPI_LEAKY) {
+    float pm = h > 0.f ? 1.f : g.slope;
+    if (g.E) pm *= g.E[(size_t)row * g.lde + col];
+    *cp = h * pm;
+    if (g.aux) g.aux[(size_t)row * g.ldaux + col] = pm;
+  } else {
+    *cp = h * g.E[(size_t)row * g.lde + col];
+  }
+}
+
+// XCD-aware tile index: workgroups are dealt round-robin over the 8 XCDs; give each XCD a contiguous run of
+// tiles (neighbours share an A row panel and adjacent B panels) so panel re-reads hit that XCD's L2.  Bijective.
+__device__ __forceinline__ int xcd_tile() {
+  const int nwg = gridDim.x, q = nwg >> 3, rem = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+}
+
+// ------------------------------------------------------------------------------------------------
+// bf16 path: float32 operands in memory, rounded to bf16 while they are staged into LDS, multiplied
+// with v_mfma_f32_16x16x32_bf16 (float32 accumulate).  Both operand kinds end up in LDS as
+// [row][k] bf16 with k contiguous (row stride 80 elements = 160 B: conflict-free ds_read_b128), so
+// one fragment read serves a whole 32-deep MFMA; m-major operands are transposed in registers
+// (4k x 4row micro-tiles) on their way in.  BKH = 64 per slab, double-buffered.
+// ------------------------------------------------------------------------------------------------
+constexpr int BKH = 64;
+constexpr int LDH = BKH + 16;   // LDS row stride in bf16 elements
+
+__device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
+  uint2 r;
+  r.x = (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
+  r.y = (uint32_t)f2bf(c) | ((uint32_t)f2bf(d) << 16);
+  return r;
+}
+
+template <int ROWS, bool MMAJ, bool VEC>
+struct StagerH {
+  static constexpr int NV = ROWS * BKH / 4 / 256;   // float4 per thread (8 for 128 rows, 4 for 64)
+  f32x4 v[NV];
+
+  __device__ __forceinline__ void load(const float* ptr, int ld, int row0, int nrows, int k0, int K) {
+    const int t = threadIdx.x;
+    if (!MMAJ) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const int idx = t + 256 * j;
+        const int r = idx / (BKH / 4), kq = idx % (BKH / 4);
+        const int row = row0 + r, k = k0 + 4 * kq;
+        v[j] = load4<VEC>(ptr + (size_t)row * ld + k, row < nrows, k, K);
+      }
+    } else {
+      // micro-tile mt = 4 k-rows x 4 rows; v[4*u + i] = k-row 4*kq+i of micro-tile u
+#pragma unroll
+      for (int u = 0; u < NV / 4; ++u) {
+        const int idx = t + 256 * u;
+        const int kq = idx / (ROWS / 4), rq = idx % (ROWS / 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int kk = k0 + 4 * kq + i, row = row0 + 4 * rq;
+          v[4 * u + i] = load4<VEC>(ptr + (size_t)kk * ld + row, kk < K, row, nrows);
+        }
+      }
+    }
+  }
+  __device__ __forceinline__ void store(u16* s) const {
+    const int t = threadIdx.x;
+    if (!MMAJ) {
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        const int idx = t + 256 * j;
+        const int r = idx / (BKH / 4), kq = idx % (BKH / 4);
+        *reinterpret_cast<uint2*>(s + r * LDH + 4 * kq) = pack4(v[j][0], v[j][1], v[j][2], v[j][3]);
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < NV / 4; ++u) {
+        const int idx = t + 256 * u;
+        const int kq = idx / (ROWS / 4), rq = idx % (ROWS / 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          *reinterpret_cast<uint2*>(s + (4 * rq + c) * LDH + 4 * kq) =
+              pack4(v[4 * u][c], v[4 * u + 1][c], v[4 * u + 2][c], v[4 * u + 3][c]);
+      }
+    }
+  }
+};
+
+template <int BM, int BN, bool TA, bool TB, bool VEC>
+__global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgs g) {
+  constexpr int TM = BM / 32, TN = BN / 32;          // 16x16 MFMA tiles per wave in each direction
+  constexpr bool A_MMAJ = TA, B_MMAJ = !TB;
+  constexpr int A_ELEMS = BM * LDH, B_ELEMS = BN * LDH;
+  __shared__ __align__(16) u16 smem[2 * (A_ELEMS + B_ELEMS)];
+
+  const int tile = xcd_tile();
+  const int bm = (tile / g.tiles_n) * BM, bn = (tile % g.tiles_n) * BN;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
+  const int lr = lane & 15, lg = lane >> 4;
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  StagerH<BM, A_MMAJ, VEC> sa;
+  StagerH<BN, B_MMAJ, VEC> sb;
+  const int nk_all = (g.K + BKH - 1) / BKH;
+  const int kt0 = blockIdx.y * g.kt_per_split;
+  const int nk = min(nk_all, kt0 + g.kt_per_split);
+
+  sa.load(g.A, g.lda, bm, g.M, kt0 * BKH, g.K);
+  sb.load(g.B, g.ldb, bn, g.N, kt0 * BKH, g.K);
+  sa.store(smem);
+  sb.store(smem + A_ELEMS);
+  __syncthreads();
+
+  int cur = 0;
+  for (int kt = kt0; kt < nk; ++kt) {
+    if (kt + 1 < nk) {
+      sa.load(g.A, g.lda, bm, g.M, (kt + 1) * BKH, g.K);
+      sb.load(g.B, g.ldb, bn, g.N, (kt + 1) * BKH, g.K);
+    }
+    const u16* As = smem + cur * (A_ELEMS + B_ELEMS);
+    const u16* Bs = As + A_ELEMS;
+#pragma unroll
+    for (int ks = 0; ks < BKH / 32; ++ks) {
+      bf16x8 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        a[i] = *reinterpret_cast<const bf16x8*>(As + (wm + 16 * i + lr) * LDH + 32 * ks + 8 * lg);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        b[j] = *reinterpret_cast<const bf16x8*>(Bs + (wn + 16 * j + lr) * LDH + 32 * ks + 8 * lg);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (kt + 1 < nk) {
+      u16* nxt = smem + (cur ^ 1) * (A_ELEMS + B_ELEMS);
+      sa.store(nxt);
+      sb.store(nxt + A_ELEMS);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // 16x16 accumulator: col = lane & 15, row = 4 * (lane >> 4) + reg
+  float* wsp = gridDim.y > 1 ? g.ws + (size_t)blockIdx.y * g.M * g.N : nullptr;
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = bn + wn + 16 * j + lr;
+      if (col >= g.N) continue;
+      const float bv = (g.bias && !wsp) ? g.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = bm + wm + 16 * i + 4 * lg + r;
+        if (row >= g.M) continue;
+        if (wsp) wsp[(size_t)row * g.N + col] = acc[i][j][r];
+        else epilogue_store(g, row, col, acc[i][j][r] + bv);
+      }
+    }
+}
+
 template <int BM, int BN, bool TA, bool TB, bool VEC>
 __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
   constexpr int TM = BM / 64, TN = BN / 64;
@@ -96,10 +270,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
   constexpr int B_ELEMS = B_MMAJ ? BK * (BN + 4) : BN * (BK + 4);
   __shared__ __align__(16) float smem[2 * (A_ELEMS + B_ELEMS)];
 
-  // Workgroups are dealt round-robin over the 8 XCDs; give each XCD a contiguous run of tiles (neighbours share
-  // an A row panel and adjacent B panels) so that panel re-reads hit that XCD's L2.  Bijective for any grid size.
-  const int nwg = gridDim.x, q = nwg >> 3, rem = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-  const int tile = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+  const int tile = xcd_tile();
   const int bm = (tile / g.tiles_n) * BM, bn = (tile % g.tiles_n) * BN;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
@@ -201,19 +372,7 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
       for (int r = 0; r < 16; ++r) {
         const int row = bm + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (row >= g.M) continue;
-        float h = acc[i][j][r] + bv;
-        float* cp = g.C + (size_t)row * g.ldc + col;
-        if (g.epi == CG_EPI_NONE) {
-          if (g.accumulate) h += *cp;
-          *cp = h;
-        } else if (g.epi == CG_EPI_LEAKY) {
-          float pm = h > 0.f ? 1.f : g.slope;
-          if (g.E) pm *= g.E[(size_t)row * g.lde + col];
-          *cp = h * pm;
-          if (g.aux) g.aux[(size_t)row * g.ldaux + col] = pm;
-        } else {
-          *cp = h * g.E[(size_t)row * g.lde + col];
-        }
+        epilogue_store(g, row, col, acc[i][j][r] + bv);
       }
     }
 }
@@ -239,21 +398,25 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(GemmArgs g, int spli
   }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool HALF = false>
 int launch_f32(const GemmArgs& g, int transA, int transB, bool vec, hipStream_t st, int splits = 1) {
   GemmArgs a = g;
   const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
   a.tiles_n = tn;
-  const int nk = (g.K + BK - 1) / BK;
+  const int bk = HALF ? BKH : BK;
+  const int nk = (g.K + bk - 1) / bk;
   a.kt_per_split = (nk + splits - 1) / splits;
   splits = (nk + a.kt_per_split - 1) / a.kt_per_split;   // no empty split
   dim3 grid(tm * tn, splits), block(256);
-#define CG_LAUNCH(TA, TB)                                                              \
-  do {                                                                                 \
-    if (vec)                                                                           \
-      hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, true>), grid, block, 0, st, a);  \
-    else                                                                               \
-      hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, false>), grid, block, 0, st, a); \
+#define CG_LAUNCH(TA, TB)                                                                    \
+  do {                                                                                       \
+    if (HALF) {                                                                              \
+      if (vec) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, TA, TB, true>), grid, block, 0, st, a);   \
+      else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, TA, TB, false>), grid, block, 0, st, a);      \
+    } else {                                                                                 \
+      if (vec) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, true>), grid, block, 0, st, a);    \
+      else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, false>), grid, block, 0, st, a);       \
+    }                                                                                        \
   } while (0)
   if (!transA && transB) CG_LAUNCH(false, true);
   else if (!transA && !transB) CG_LAUNCH(false, false);
@@ -286,7 +449,8 @@ extern "C" int cg_gemm(float* C, int ldc, const void* A, int lda, const void* B,
   if (lda < a_cols || ldb < b_cols || ldc < N) return CG_ERR_BAD_ARG;
   if (E && lde < N) return CG_ERR_BAD_ARG;
   if (aux && ldaux < N) return CG_ERR_BAD_ARG;
-  if (dtype != CG_F32) return CG_ERR_UNSUPPORTED;
+  if (dtype != CG_F32 && dtype != CG_BF16) return CG_ERR_UNSUPPORTED;
+  const bool half = dtype == CG_BF16;
   hipStream_t st = (hipStream_t)stream;
   GemmArgs g{(const float*)A, (const float*)B, C, bias, E, aux, M, N, K, lda, ldb, ldc, lde, ldaux,
              epi, accumulate, slope, 0, 1 << 30, (float*)workspace};
@@ -294,16 +458,18 @@ extern "C" int cg_gemm(float* C, int ldc, const void* A, int lda, const void* B,
   // Tile and split-K choice by a small cost model: a K slab of a tile costs max(MFMA cycles, staged bytes at
   // ~10 B/clk/CU); the launch takes ceil(blocks / 256 CUs) rounds of (slabs per split) such slabs, plus the slab
   // round trip of the partial sums when K is split.  Large tiles stage fewer bytes per FLOP, splits fill the chip.
-  const int nk = (K + BK - 1) / BK;
+  // (bf16: a 64-deep slab is bound by the float32 bytes staged, ~20 B/clk/CU from L2.)
+  const int nk = half ? (K + BKH - 1) / BKH : (K + BK - 1) / BK;
   const size_t per = (size_t)M * N * sizeof(float);
-  struct Cand { int bm, bn; double slab; } cands[3] = {{128, 128, 4096.0}, {128, 64, 2458.0}, {64, 64, 1638.0}};
+  struct Cand { int bm, bn; double slab; } cands[3] = {{128, 128, half ? 3277.0 : 4096.0},
+                                                       {128, 64, 2458.0}, {64, 64, 1638.0}};
   int best = 2, best_splits = 1;
   double best_cost = 1e300;
   for (int c = 0; c < 3; ++c) {
     const long tiles = (long)((M + cands[c].bm - 1) / cands[c].bm) * ((N + cands[c].bn - 1) / cands[c].bn);
     int smax = 1;
-    if (workspace && nk >= 16) {
-      smax = nk / 8;
+    if (workspace && nk >= (half ? 8 : 16)) {
+      smax = nk / (half ? 4 : 8);
       if (smax > 32) smax = 32;
       if ((size_t)smax * per > workspace_bytes) smax = (int)(workspace_bytes / per);
       if (smax < 1) smax = 1;
@@ -316,6 +482,11 @@ extern "C" int cg_gemm(float* C, int ldc, const void* A, int lda, const void* B,
       if (sp > 1) cost += 2.0 * sp * (double)per / (256.0 * 10.0) + 4000.0;
       if (cost < best_cost) { best_cost = cost; best = c; best_splits = sp; }
     }
+  }
+  if (half) {
+    if (best == 0) return launch_f32<128, 128, true>(g, transA, transB, vec, st, best_splits);
+    if (best == 1) return launch_f32<128, 64, true>(g, transA, transB, vec, st, best_splits);
+    return launch_f32<64, 64, true>(g, transA, transB, vec, st, best_splits);
   }
   if (best == 0) return launch_f32<128, 128>(g, transA, transB, vec, st, best_splits);
   if (best == 1) return launch_f32<128, 64>(g, transA, transB, vec, st, best_splits);

@@ -42,7 +42,14 @@ class HipOps:
 
     name = "hip"
 
-    def __init__(self, device=None):
+    def __init__(self, device=None, precision="fp32"):
+        """precision: 'fp32' - every product on the exact float32 MFMA;
+        'bf16' - the large dense-layer products (forward, input gradient, weight gradient with
+        M, N >= 128 and K >= 256) round their operands to bf16 and use the bf16 MFMA with float32
+        accumulation; the 16-wide token layers, critic head and embedding products stay float32."""
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        self.precision = precision
         if not torch.cuda.is_available():
             raise RuntimeError("cycle-gan-rna_amd needs a HIP device (torch.cuda.is_available() is False)")
         self.lib = _lib.load()
@@ -84,7 +91,7 @@ class HipOps:
 
     # -- GEMM -----------------------------------------------------------------
     def gemm(self, Cm, A, B, transA=False, transB=False, bias=None, epi=EPI_NONE, E=None, aux=None, slope=0.0,
-             accumulate=False):
+             accumulate=False, dtype=None):
         _chk(Cm), _chk(A), _chk(B)
         M, N = Cm.shape
         K = A.shape[0] if transA else A.shape[1]
@@ -97,11 +104,13 @@ class HipOps:
             assert tuple(E.shape) == (M, N)
         if aux is not None:
             assert tuple(aux.shape) == (M, N)
+        if dtype is None:
+            dtype = 1 if (self.precision == "bf16" and M >= 128 and N >= 128 and K >= 256) else 0
         if self._gemm_events is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(self.device))
         st = self.lib.cg_gemm(_ptr(Cm), _ld(Cm), _ptr(A), _ld(A), _ptr(B), _ld(B), M, N, K, int(transA), int(transB),
-                              0, _ptr(bias), epi, _ptr(E), _ld(E), _ptr(aux), _ld(aux), float(slope),
+                              dtype, _ptr(bias), epi, _ptr(E), _ld(E), _ptr(aux), _ld(aux), float(slope),
                               int(accumulate), _ptr(self._gemm_ws), self._gemm_ws.numel() * 4, self._stream())
         if self._gemm_events is not None:
             e1.record(torch.cuda.current_stream(self.device))
@@ -253,7 +262,7 @@ class HipOps:
         assert Cn.shape[1] == A.shape[1] and labels.shape[0] == A.shape[0]
         p, n = self._slot(red, slot)
         st = self.lib.cg_reduce_centroid_sq(p, n, _ptr(A), _ld(A), _ptr(Cn), _ld(Cn), _ptr(labels), labels.stride(0),
-                                            A.shape[0], A.shape[1], self._stream())
+                                            A.shape[0], A.shape[1], Cn.shape[0], self._stream())
         _lib.check(st, "cg_reduce_centroid_sq")
 
     def reduce_kl(self, red, slot, ml):
@@ -283,8 +292,8 @@ class HipOps:
     def centroid_bwd(self, dA, A, Cn, labels, coef, idx, scale, accumulate=False):
         M, N = A.shape
         st = self.lib.cg_centroid_bwd(_ptr(dA), _ld(dA), _ptr(A), _ld(A), _ptr(Cn), _ld(Cn), _ptr(labels),
-                                      labels.stride(0), _ptr(coef), idx, float(scale), M, N, int(accumulate),
-                                      self._stream())
+                                      labels.stride(0), _ptr(coef), idx, float(scale), M, N, Cn.shape[0],
+                                      int(accumulate), self._stream())
         _lib.check(st, "cg_centroid_bwd")
 
     def fm_bwd(self, dF, mean_fake, mean_real, coef, idx, scale, accumulate=False):

@@ -52,7 +52,8 @@ int cg_version(void);
  *   transA = 0: A is stored [M][K];  1: A is stored [K][M]
  *   transB = 0: B is stored [K][N];  1: B is stored [N][K]
  *   dtype  = CG_F32 (v_mfma_f32_32x32x2_f32, exact float32 products) or
- *            CG_BF16 (A and B are bf16 bit patterns, v_mfma_f32_16x16x32_bf16)
+ *            CG_BF16 (A and B are still float32 in memory; they are rounded to bf16 while being
+ *            staged into LDS and multiplied with v_mfma_f32_16x16x32_bf16, float32 accumulate)
  * Replaces nn.Linear forward (GAN_functions.py:59,62,89,92,97-98,117,120,124,
  * 165,169,172,174; transA=0, transB=1), its input gradient (0,0), its weight
  * gradient (1,0), and the second-order products of the gradient penalty
@@ -190,9 +191,9 @@ int cg_gp_penalty(float* V, int ldv, float* rowpen, const float* UX, int ldu, fl
 int cg_reduce_sum(float* parts, int* nparts, const float* X, int ldx, int M, int N, void* stream);
 /* sum |A - B| (L1 cycle loss :353-357). */
 int cg_reduce_l1(float* parts, int* nparts, const float* A, int lda, const float* B, int ldb, int M, int N, void* stream);
-/* sum (A[m,:] - C[labels[m],:])^2 (cell-type centroid MSE :359-364). */
+/* sum (A[m,:] - C[labels[m],:])^2 (cell-type centroid MSE :359-364); labels are clamped to [0, n_types). */
 int cg_reduce_centroid_sq(float* parts, int* nparts, const float* A, int lda, const float* C, int ldc,
-                          const int64_t* labels, int lstride, int M, int N, void* stream);
+                          const int64_t* labels, int lstride, int M, int N, int n_types, void* stream);
 /* sum of (1 + lv - mu^2 - exp(lv)) over [mu | lv] rows (KL :375-376). */
 int cg_reduce_kl(float* parts, int* nparts, const float* ml, int ldml, int M, int L, void* stream);
 /* out[n] (+)= scale * sum_m X[m,n]: column means (feature matching :368,:372; scale = 1/M) and the
@@ -211,7 +212,7 @@ int cg_l1_bwd(float* dA, int ldd, const float* A, int lda, const float* B, int l
 /* dA (+)= coef[idx]*scale*(A[m,:] - C[labels[m],:]) (gradient of the centroid MSE). */
 int cg_centroid_bwd(float* dA, int ldd, const float* A, int lda, const float* C, int ldc,
                     const int64_t* labels, int lstride, const float* coef, int idx, float scale,
-                    int M, int N, int accumulate, void* stream);
+                    int M, int N, int n_types, int accumulate, void* stream);
 /* dF[m,n] (+)= coef[idx]*scale*(mf[n]-mr[n]) for every row (gradient of the feature-matching MSE). */
 int cg_fm_bwd(float* dF, int ldd, const float* mean_fake, const float* mean_real,
               const float* coef, int idx, float scale, int M, int N, int accumulate, void* stream);

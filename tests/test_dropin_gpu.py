@@ -153,3 +153,89 @@ def test_train_function_against_reference(tag):
     init = build_modules(gm, gh, cfg, fx["init_seed"])[2].state_dict()["model.4.weight"].reshape(-1).double()[::ref_final["stride"]]
     upd_ref = ref_final["values"].double() - init
     assert float((got - ref_final["values"].double()).norm() / upd_ref.norm()) <= 0.35
+
+
+def _oracle_state(module):
+    return {k: v.detach().cpu().clone() for k, v in module.state_dict().items()}
+
+
+@pytest.mark.parametrize("sparse,with_labels,gm,gh", [(False, False, 37, 50), (True, True, 64, 41)])
+def test_modules_against_oracle_edge_configurations(sparse, with_labels, gm, gh):
+    """cat_covs=None (zero embeddings, GAN_functions.py:136-137,182-183), the sparse-attention class
+    (extra unused `gate` parameters), and gene counts that are odd / not multiples of 4 (unaligned
+    weight column slices take the scalar-load path of the GEMM)."""
+    from cycle_gan_rna_amd import GAN_functions as F
+    from cycle_gan_rna_amd.noise import HostReplayNoise
+    from oracle import cyclegan_oracle as O
+    cfg = O.default_config(hidden_dims=[96, 64, 32], preprocess_type="log_normalized", use_sparse_attention=sparse)
+    g_m2h, g_h2m, d_m, d_h = build_modules(gm, gh, cfg, 5)
+    if sparse:
+        assert "residual_attention_blocks.0.1.gate.weight" in g_m2h.state_dict()
+    dev = torch.device("cuda:0")
+    B = 12
+    xm, _ = O.synthetic_expression(B, gm, 12, seed=1)
+    lab = O.balanced_labels(B, 12, 2)[:, None] if with_labels else None
+    dlab = None if lab is None else lab.to(dev)
+    Pg, Pd = _oracle_state(g_m2h), _oracle_state(d_h)
+    for P in (Pg, Pd):
+        for k in O.param_names(P):
+            P[k].requires_grad_(True)
+    # oracle
+    torch.manual_seed(3)
+    nz = O.GlobalRngNoise()
+    out, mu, lv = O.generator_forward(Pg, xm, lab, cfg, nz, train=True)
+    val, feat = O.discriminator_forward(Pd, out, lab, nz)
+    (val.mean() + 0.1 * feat.pow(2).mean() + 0.01 * (mu * lv).mean()).backward()
+    # drop-in modules on the GPU, same draws replayed from the host generator
+    torch.manual_seed(3)
+    src = HostReplayNoise(dev)
+    g_m2h._noise_source = src
+    d_h._noise_source = src
+    o2, mu2, lv2 = g_m2h(xm.to(dev), dlab)
+    v2, f2 = d_h(o2, dlab, return_features=True)
+    (v2.mean() + 0.1 * f2.pow(2).mean() + 0.01 * (mu2 * lv2).mean()).backward()
+    assert rel(o2, out) <= 2e-4 and rel(v2, val) <= 2e-4 and rel(f2, feat) <= 2e-4
+    for mod, P in ((g_m2h, Pg), (d_h, Pd)):
+        params = dict(mod.named_parameters())
+        floor = 1e-3 * max(float(P[k].grad.abs().max()) for k in O.param_names(P) if P[k].grad is not None)
+        for k in O.param_names(P):
+            if P[k].grad is None:            # unused parameters (gate; embeddings without labels)
+                assert params[k].grad is None or float(params[k].grad.abs().max()) == 0.0, k
+                continue
+            assert rel(params[k].grad, P[k].grad, floor) <= 1.0, (k, rel(params[k].grad, P[k].grad, floor))
+
+
+def test_standalone_blocks_match_torch_modules():
+    """ResidualBlock and GeneSelfAttention used on their own (eval mode: no dropout) against the
+    torch.nn layers they wrap, forward and backward."""
+    from cycle_gan_rna_amd import GAN_functions as F
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    x = torch.randn(6, 16, 16)
+    rb = F.ResidualBlock(16).to(dev)
+    xr = x.to(dev).requires_grad_(True)
+    y = rb(xr)                                     # train mode: batch statistics
+    y.square().sum().backward()
+    xc = x.clone().requires_grad_(True)
+    blk = torch.nn.Sequential(torch.nn.Linear(16, 16), torch.nn.BatchNorm1d(16), torch.nn.ReLU(), torch.nn.Linear(16, 16),
+                              torch.nn.BatchNorm1d(16))
+    sd = {k: v.cpu() for k, v in rb.block.state_dict().items()}
+    sd["1.running_mean"].zero_(), sd["1.running_var"].fill_(1), sd["4.running_mean"].zero_(), sd["4.running_var"].fill_(1)
+    blk.load_state_dict(sd)
+    ye = xc + blk(xc.view(96, 16)).view(6, 16, 16)
+    ye.square().sum().backward()
+    assert rel(y, ye) <= 2e-4 and rel(xr.grad, xc.grad, 1e-3 * float(xc.grad.abs().max())) <= 1.0
+    assert rel(rb.block[0].weight.grad, blk[0].weight.grad, 1e-3 * float(blk[0].weight.grad.abs().max())) <= 1.0
+    at = F.GeneSelfAttention(16, 4).to(dev).eval()
+    xa = x.to(dev).requires_grad_(True)
+    ya = at(xa)
+    ya.square().sum().backward()
+    ref = torch.nn.MultiheadAttention(16, 4, dropout=0.1, batch_first=True).eval()
+    ref.load_state_dict({k: v.cpu() for k, v in at.attention.state_dict().items()})
+    ln = torch.nn.LayerNorm(16)
+    ln.load_state_dict({k: v.cpu() for k, v in at.norm.state_dict().items()})
+    xb = x.clone().requires_grad_(True)
+    yb = ln(xb + ref(xb, xb, xb)[0])
+    yb.square().sum().backward()
+    assert rel(ya, yb) <= 2e-4 and rel(xa.grad, xb.grad, 1e-3 * float(xb.grad.abs().max())) <= 1.0
+    assert rel(at.attention.in_proj_weight.grad, ref.in_proj_weight.grad, 1e-3 * float(ref.in_proj_weight.grad.abs().max())) <= 1.0

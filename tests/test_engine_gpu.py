@@ -23,7 +23,8 @@ pytestmark = pytest.mark.gpu
 
 # g_adv = -mean D(fake_h) - mean D(fake_m) is a difference of O(0.1-1) critic
 # outputs that passes through zero; its error is judged against that scale.
-FLOOR = {"g_adv": 0.5}
+# g_loss is a weighted sum in which the adversarial term enters with either sign; same treatment.
+FLOOR = {"g_adv": 0.5, "g_loss": 0.5}
 
 
 @pytest.fixture(scope="module")
@@ -56,7 +57,7 @@ def run_both(ops, cfg, gm, gh, B, iters, seed=11):
 
 
 @pytest.mark.parametrize("ptype,gm,gh,B", [("log_normalized", 48, 40, 16), ("counts", 64, 64, 24),
-                                           ("log_normalized", 200, 200, 32)])
+                                           ("log_normalized", 200, 200, 32), ("log_normalized", 50, 37, 16)])
 def test_iterations_match_oracle(ops, ptype, gm, gh, B):
     cfg = small_cfg(preprocess_type=ptype, nb_critic=2)
     nets, tr, eng, exp, got = run_both(ops, cfg, gm, gh, B, iters=5)      # generator steps at i = 0, 2, 4
@@ -165,3 +166,20 @@ def test_graph_replay_equals_eager(ops):
     assert n0 == n1
     assert torch.equal(d0, d1) and torch.equal(g0, g1)
     assert o0["g_loss"] == o1["g_loss"] and o0["d_m_loss"] == o1["d_m_loss"]
+
+
+def test_bf16_mfma_path_within_stated_tolerance():
+    """precision='bf16': the large dense-layer products run on the bf16 MFMA (operands rounded to bf16,
+    float32 accumulation).  Against the float32 oracle on the same seeds and noise: every loss within
+    rel 2e-2 over the first generator steps (the stated bf16 tolerance).  Generated cells are checked
+    through their mean absolute deviation, which measures 8e-2 of the mean absolute value at the first step
+    (bound 1.5e-1): the outputs are small differences of O(1) terms after eight bf16 layers, so they miss
+    the 2e-2 that the losses meet."""
+    from cycle_gan_rna_amd.ops import HipOps
+    cfg = O.default_config(preprocess_type="log_normalized", nb_critic=2)
+    nets, tr, eng, exp, got = run_both(HipOps("cuda:0", precision="bf16"), cfg, 512, 512, 256, iters=3)
+    for i in (0, 2):
+        for k in LOSS_KEYS:
+            assert rel(got[i][k], exp[i][k], FLOOR.get(k, 0.0)) <= 2e-2, (i, k, got[i][k], exp[i][k])
+        d = (got[i]["fake_human"].double() - exp[i]["fake_human"].double()).abs().mean()
+        assert float(d / exp[i]["fake_human"].double().abs().mean()) <= 1.5e-1, (i, float(d))

@@ -60,6 +60,35 @@ def test_gemm_plain(ops, M, N, K, ta, tb):
     close(got, exp, 2e-5, "gemm")
 
 
+@pytest.mark.parametrize("M,N,K,ta,tb", [(128, 128, 256, 0, 1), (512, 2048, 5000, 0, 1), (512, 5000, 1024, 0, 0),
+                                         (1024, 5012, 512, 1, 0), (130, 300, 517, 0, 0), (257, 129, 263, 1, 0),
+                                         (200, 136, 300, 1, 1), (512, 1024, 2048, 0, 1)])
+def test_gemm_bf16(ops, M, N, K, ta, tb):
+    """bf16 MFMA path: operands rounded to bf16 on the fly, float32 accumulation.  The expectation is the
+    float64 product of the bf16-rounded operands, so only the accumulation order differs (rtol 2e-5)."""
+    A = rnd(*((K, M) if ta else (M, K)), seed=1)
+    B = rnd(*((N, K) if tb else (K, N)), seed=2)
+    bias = rnd(N, seed=3)
+    exp = torch.empty(M, N, dtype=torch.float64)
+    cpu.gemm(exp, A.bfloat16().double(), B.bfloat16().double(), ta, tb, bias=bias.double())
+    got = torch.full((M, N), float("nan")).cuda()
+    ops.gemm(got, dev(A), dev(B), ta, tb, bias=dev(bias), dtype=1)
+    close(got, exp, 2e-5, "gemm bf16")
+    # and against the unrounded product: bf16 has 8 significand bits
+    exact = torch.empty(M, N, dtype=torch.float64)
+    cpu.gemm(exact, A.double(), B.double(), ta, tb, bias=bias.double())
+    close(got, exact, 2e-2, "gemm bf16 vs float64")
+
+
+def test_gemm_bf16_exact_on_small_integers(ops):
+    M, N, K = 96, 160, 200
+    A = torch.randint(-3, 4, (K, M), generator=torch.Generator().manual_seed(0)).float()
+    B = (torch.arange(K * N).reshape(K, N) % 7 - 3).float()
+    got = torch.zeros(M, N).cuda()
+    ops.gemm(got, dev(A), dev(B), True, False, dtype=1)
+    assert torch.equal(got.cpu(), A.t() @ B)
+
+
 def test_gemm_is_exact_fp32_fma_chain(ops):
     """Small-integer data: every product and sum is exact, so any slip in the k
     coverage or in the lane -> (row, col) map shows as an integer difference.

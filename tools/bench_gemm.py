@@ -15,7 +15,7 @@ SHAPES = [  # name, M, N, K, transA, transB
 ]
 
 def main():
-    ops = HipOps("cuda:0")
+    ops = HipOps("cuda:0", precision=sys.argv[1] if len(sys.argv) > 1 else "fp32")
     g = torch.Generator(device="cuda").manual_seed(0)
     tot_t = tot_f = 0.0
     for name, M, N, K, ta, tb in SHAPES:
