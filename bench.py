@@ -164,14 +164,23 @@ def main():
                 ops.gemm_untimed(filler_c, filler_a, filler_a, False, True)
             step(i)
         torch.cuda.synchronize()
-        n_launch, gemm_ms, exec_flop = ops.end_gemm_timing()
+        n_launch, gemm_ms, exec_flop, gemm_bytes = ops.end_gemm_timing()
+        # HBM bytes per GEMM launch measured with rocprofv3 PMC passes of this same workload (tools/pmc_summary.py);
+        # the summary is committed under profiles/ because counters cannot be collected from inside this process
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_pmc_%s.json" % ("bf16" if a.dtype == "bf16" else "f32"))
+        if os.path.exists(pmc) and (G, B) == (G_GENES, BATCH):
+            k = json.load(open(pmc))["kernels"]
+            fam = [k[n] for n in ("gemm_f32", "gemm_bf16") if n in k]
+            traffic = sum(f["hbm_bytes_per_launch"] * f["launches"] for f in fam) / sum(f["launches"] for f in fam)
         alg_flop = algorithmic_gflop_per_cell_iteration(G) * 1e9 * B * NB_CRITIC
         achieved = alg_flop / (gemm_ms * 1e-3) / 1e12
         peak = BF16_MFMA_PEAK_TFLOPS if a.dtype == "bf16" else F32_MFMA_PEAK_TFLOPS
         kname = ("gemm_bf16_kernel (v_mfma_f32_16x16x32_bf16) + gemm_f32_kernel for the small products"
                  if a.dtype == "bf16" else "gemm_f32_kernel (v_mfma_f32_32x32x2_f32)")
         roof = dict(bound="mfma", achieved=achieved, peak=peak, unit="TFLOP/s",
-                    frac=achieved / peak, traffic=None,
+                    frac=achieved / peak, traffic=traffic, traffic_unit="HBM bytes per launch (rocprofv3 PMC)",
+                    operand_bytes_per_launch=gemm_bytes / n_launch,
                     kernel=kname, launches_per_iteration=n_launch / NB_CRITIC,
                     avg_launch_us=gemm_ms * 1e3 / n_launch, gemm_ms_per_iteration=gemm_ms / NB_CRITIC,
                     executed_tflops=exec_flop / (gemm_ms * 1e-3) / 1e12)

@@ -71,10 +71,11 @@ class HipOps:
         self._gemm_events = []
 
     def end_gemm_timing(self):
-        """Returns (launches, total milliseconds, executed FLOP) since begin_gemm_timing()."""
+        """Returns (launches, total milliseconds, executed FLOP, operand + result bytes) since begin_gemm_timing()."""
         torch.cuda.synchronize(self.device)
         ev, self._gemm_events = self._gemm_events, None
-        return len(ev), sum(a.elapsed_time(b) for a, b, _ in ev), sum(f for _, _, f in ev)
+        return (len(ev), sum(a.elapsed_time(b) for a, b, _, _ in ev), sum(f for _, _, f, _ in ev),
+                sum(by for _, _, _, by in ev))
 
     # -- plumbing -------------------------------------------------------------
     def _stream(self):
@@ -114,7 +115,8 @@ class HipOps:
                               int(accumulate), _ptr(self._gemm_ws), self._gemm_ws.numel() * 4, self._stream())
         if self._gemm_events is not None:
             e1.record(torch.cuda.current_stream(self.device))
-            self._gemm_events.append((e0, e1, 2.0 * M * N * K))
+            self._gemm_events.append((e0, e1, 2.0 * M * N * K,
+                                      4.0 * (M * K + K * N + M * N * (2 if accumulate else 1))))
         _lib.check(st, "cg_gemm")
 
     def gemm_untimed(self, *args, **kw):
