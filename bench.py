@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32: exact float32 MFMA everywhere; bf16: large dense-layer products on the bf16 MFMA")
+    ap.add_argument("--sequential", action="store_true", help="one stream instead of two")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying HIP graphs")
     a = ap.parse_args()
 
@@ -116,6 +117,8 @@ def main():
     eng = StepEngine(nets, cfg, cm, ch, ops, B)
     xm, xh, lm, lh = xm.to(dev), xh.to(dev), lm[:, None].to(dev), lh[:, None].to(dev)
     noise = DeviceNoise(dev, seed=1 + rank, default_generator=True)
+    if not a.sequential:
+        eng.enable_concurrency()
     if not a.eager and world == 1:
         eng.enable_graphs()
 

@@ -541,11 +541,37 @@ class StepEngine:
         self._d_scales_b = None
         self._pin = None
         self.use_graphs = False
+        self.concurrent = False
+        self.d_feat2 = Z(B, 256)
         from .ddp import GradSync
         self.sync = GradSync(ops.device)
         self.g_tot = Z(10, dtype=torch.float64)
         self.g_slots = ops.to_device(torch.arange(S_ADV_H, S_ADV_H + 10, dtype=torch.int32))
         self.g_ones = ops.to_device(torch.ones(10, dtype=torch.float64))
+
+    # ---- two-stream concurrency ------------------------------------------------------
+    def enable_concurrency(self):
+        """Run the mouse->human and human->mouse halves of a step (and the two critics) on two HIP
+        streams.  They are independent between a few join points, and most kernels of one half
+        leave much of the chip idle at batch 512, so the halves overlap.  Only for noise that is
+        drawn on the device: the order of draws then differs from the reference's call order."""
+        self.side = torch.cuda.Stream(device=self.ops.device)
+        self.ops.prepare_stream(self.side)
+        self.ops.prepare_stream(torch.cuda.current_stream(self.ops.device))
+        self.concurrent = True
+
+    def _two(self, first, second):
+        """Run first() on the current stream and second() on the side stream, then join."""
+        if not self.concurrent:
+            first()
+            second()
+            return
+        main = torch.cuda.current_stream(self.ops.device)
+        self.side.wait_stream(main)          # the side stream starts from what the main stream has queued so far
+        first()                              # (host call order stays first, second: noise is drawn in the same
+        with torch.cuda.stream(self.side):   #  order as in a sequential run)
+            second()
+        main.wait_stream(self.side)
 
     # ---- optimizer ---------------------------------------------------------------
     def set_lr(self, lr):
@@ -620,11 +646,14 @@ class StepEngine:
         ops, cfg = self.ops, self.cfg
         b = mouse.shape[0]
         self.arena_d.g.zero_()
-        fake_human = self.gen_a["g_m2h"].forward(mouse, mouse_cat, noise)
-        fake_mouse = self.gen_a["g_h2m"].forward(human, human_cat, noise)
-        plan = (("d_m", mouse, mouse_cat, fake_mouse, human_cat, S_DM_REAL),
-                ("d_h", human, human_cat, fake_human, mouse_cat, S_DH_REAL))
-        for name, real, real_lab, fake, fake_lab, s0 in plan:
+        out = {}
+
+        def gen(which, x, lab):
+            out[which] = self.gen_a[which].forward(x, lab, noise)
+        self._two(lambda: gen("g_m2h", mouse, mouse_cat), lambda: gen("g_h2m", human, human_cat))
+        fake_human, fake_mouse = out["g_m2h"], out["g_h2m"]
+
+        def critic(name, real, real_lab, fake, fake_lab, s0):
             dp = self.disc[name][0]
             val, _ = dp.forward(real, real_lab, noise)
             ops.reduce_sum(self.red, s0, val)
@@ -637,7 +666,10 @@ class StepEngine:
             ops.gp_interp(xhat, real, fake, alpha)
             dp.forward(xhat, fake_lab, noise)
             dp.gp_backward(cfg["lambda_gp"], self.red, s0 + 2)
-            self.sync.launch(self.arena_d.net_grad(name))
+        self._two(lambda: critic("d_m", mouse, mouse_cat, fake_mouse, human_cat, S_DM_REAL),
+                  lambda: critic("d_h", human, human_cat, fake_human, mouse_cat, S_DH_REAL))
+        self.sync.launch(self.arena_d.net_grad("d_m"))
+        self.sync.launch(self.arena_d.net_grad("d_h"))
         self.sync.wait()
         self._adam(self.arena_d)
         ops.sum_parts(self.d_tot, self.red, self.d_slots, self.d_scales)
@@ -664,34 +696,43 @@ class StepEngine:
         gm, gh = self.g_mouse, self.g_human
         self.arena_g.g.zero_()
         A, Bp = self.gen_a["g_m2h"], self.gen_a["g_h2m"]
-        fake_human = A.forward(mouse, mouse_cat, noise)
-        fake_mouse = Bp.forward(human, human_cat, noise)
+        Rm, Rh = self.gen_b["g_h2m"], self.gen_b["g_m2h"]
         dh_adv, dh_fm, dh_tmp = self.disc["d_h"]
         dm_adv, dm_fm, dm_tmp = self.disc["d_m"]
-        val_h, _ = dh_adv.forward(fake_human, human_cat, noise)            # :347
-        val_m, _ = dm_adv.forward(fake_mouse, mouse_cat, noise)
-        Rm, Rh = self.gen_b["g_h2m"], self.gen_b["g_m2h"]
-        recov_mouse = Rm.forward(fake_human, human_cat, noise)             # :349-350
-        recov_human = Rh.forward(fake_mouse, mouse_cat, noise)
-        red = self.red
-        ops.reduce_sum(red, S_ADV_H, val_h)
-        ops.reduce_sum(red, S_ADV_M, val_m)
-        ops.reduce_l1(red, S_CYC_M, recov_mouse, mouse)                    # :353-357
-        ops.reduce_l1(red, S_CYC_H, recov_human, human)
-        ops.reduce_centroid_sq(red, S_CT_H, fake_human, self.human_centroids, mouse_cat)   # :363
-        ops.reduce_centroid_sq(red, S_CT_M, fake_mouse, self.mouse_centroids, human_cat)   # :364
-        _, f = dh_tmp.forward(human, human_cat, noise)                     # :366-368
-        ops.colsum(self.fm_mean["h_real"], f, 1.0 / b)
-        _, f = dh_fm.forward(fake_human, human_cat, noise)
-        ops.colsum(self.fm_mean["h_fake"], f, 1.0 / b)
-        ops.reduce_sqdiff(red, S_FM_H, self.fm_mean["h_real"], self.fm_mean["h_fake"])
-        _, f = dm_tmp.forward(mouse, mouse_cat, noise)                     # :370-372
-        ops.colsum(self.fm_mean["m_real"], f, 1.0 / b)
-        _, f = dm_fm.forward(fake_mouse, mouse_cat, noise)
-        ops.colsum(self.fm_mean["m_fake"], f, 1.0 / b)
-        ops.reduce_sqdiff(red, S_FM_M, self.fm_mean["m_real"], self.fm_mean["m_fake"])
-        ops.reduce_kl(red, S_KL_H, A.ml[:b])                               # :375-376
-        ops.reduce_kl(red, S_KL_M, Bp.ml[:b])
+        red, o = self.red, {}
+        # Forward, in the reference's call order (:344-372).  Each pair below is independent and may run on two
+        # streams; the human-side member comes first, as in the reference, so a sequential run draws its noise in
+        # the reference's order.
+
+        def fwd(key, p, x, lab):
+            o[key] = p.forward(x, lab, noise)
+        self._two(lambda: fwd("fh", A, mouse, mouse_cat), lambda: fwd("fm", Bp, human, human_cat))
+        fake_human, fake_mouse = o["fh"], o["fm"]
+
+        def adv(dp, x, lab, slot):
+            val, _ = dp.forward(x, lab, noise)                              # :347
+            ops.reduce_sum(red, slot, val)
+        self._two(lambda: adv(dh_adv, fake_human, human_cat, S_ADV_H), lambda: adv(dm_adv, fake_mouse, mouse_cat, S_ADV_M))
+
+        def cyc(key, p, x, lab, target, slot):
+            o[key] = p.forward(x, lab, noise)                               # :349-357
+            ops.reduce_l1(red, slot, o[key], target)
+        self._two(lambda: cyc("rm", Rm, fake_human, human_cat, mouse, S_CYC_M),
+                  lambda: cyc("rh", Rh, fake_mouse, mouse_cat, human, S_CYC_H))
+        recov_mouse, recov_human = o["rm"], o["rh"]
+
+        def ct_fm(fake, cents, src_lab, s_ct, d_tmp, d_fm, real, lab, m_real, m_fake, s_fm, gen_first, s_kl):
+            ops.reduce_centroid_sq(red, s_ct, fake, cents, src_lab)         # :363-364
+            _, f = d_tmp.forward(real, lab, noise)                          # :366-372
+            ops.colsum(self.fm_mean[m_real], f, 1.0 / b)
+            _, f = d_fm.forward(fake, lab, noise)
+            ops.colsum(self.fm_mean[m_fake], f, 1.0 / b)
+            ops.reduce_sqdiff(red, s_fm, self.fm_mean[m_real], self.fm_mean[m_fake])
+            ops.reduce_kl(red, s_kl, gen_first.ml[:b])                      # :375-376
+        self._two(lambda: ct_fm(fake_human, self.human_centroids, mouse_cat, S_CT_H, dh_tmp, dh_fm, human, human_cat,
+                                "h_real", "h_fake", S_FM_H, A, S_KL_H),
+                  lambda: ct_fm(fake_mouse, self.mouse_centroids, human_cat, S_CT_M, dm_tmp, dm_fm, mouse, mouse_cat,
+                                "m_real", "m_fake", S_FM_M, Bp, S_KL_M))
         L = cfg["latent_dim"]
         if self.sync.enabled:
             # every rank must derive the same loss scales: replace the local loss sums by their sum over ranks
@@ -713,25 +754,23 @@ class StepEngine:
                           float(cfg["lambda_fm"]), float(cfg["lambda_kl"])]
         ops.gloss_finalize(self.ema, self.gloss, self.coef, red, desc)     # :380-406
         coef = self.coef
-        # ---- backward: gradient w.r.t. fake_human / fake_mouse from the four loss terms ----
+        # ---- backward.  Human side: everything that produces d(loss)/d(fake_human) (and g_h2m's gradients through
+        # the cycle pass); mouse side likewise; then each first-pass generator.  The two sides touch disjoint buffers.
         dfh, dfm = self.d_fake["human"][:b], self.d_fake["mouse"][:b]
-        ops.centroid_bwd(dfh, fake_human, self.human_centroids, mouse_cat, coef, 2, 2.0 / (b * gh))
-        ops.centroid_bwd(dfm, fake_mouse, self.mouse_centroids, human_cat, coef, 2, 2.0 / (b * gm))
-        dh_adv.backward(coef, 0, -1.0 / b, param_grads=False, dx_out=dfh)
-        dm_adv.backward(coef, 0, -1.0 / b, param_grads=False, dx_out=dfm)
-        dfe = self.d_feat[:b]
-        ops.fm_bwd(dfe, self.fm_mean["h_fake"], self.fm_mean["h_real"], coef, 3, 1.0 / (256 * b))
-        dh_fm.backward(None, dfeat=dfe, param_grads=False, dx_out=dfh)
-        ops.fm_bwd(dfe, self.fm_mean["m_fake"], self.fm_mean["m_real"], coef, 3, 1.0 / (256 * b))
-        dm_fm.backward(None, dfeat=dfe, param_grads=False, dx_out=dfm)
-        drm, drh = self.d_recov["mouse"][:b], self.d_recov["human"][:b]
-        ops.l1_bwd(drm, recov_mouse, mouse, coef, 1, 1.0 / (b * gm))
-        Rm.backward(drm, need_dx=True, dx_out=dfh, dx_accumulate=True)
-        ops.l1_bwd(drh, recov_human, human, coef, 1, 1.0 / (b * gh))
-        Rh.backward(drh, need_dx=True, dx_out=dfm, dx_accumulate=True)
-        A.backward(dfh, kl=(coef, 4, 1.0))
+
+        def side(dfake, fake, cents, src_lab, gdim, d_adv, d_fm, m_fake, m_real, dfe, drec, recov, target, tdim, R):
+            ops.centroid_bwd(dfake, fake, cents, src_lab, coef, 2, 2.0 / (b * gdim))
+            d_adv.backward(coef, 0, -1.0 / b, param_grads=False, dx_out=dfake)
+            ops.fm_bwd(dfe, self.fm_mean[m_fake], self.fm_mean[m_real], coef, 3, 1.0 / (256 * b))
+            d_fm.backward(None, dfeat=dfe, param_grads=False, dx_out=dfake)
+            ops.l1_bwd(drec, recov, target, coef, 1, 1.0 / (b * tdim))
+            R.backward(drec, need_dx=True, dx_out=dfake, dx_accumulate=True)
+        self._two(lambda: side(dfh, fake_human, self.human_centroids, mouse_cat, gh, dh_adv, dh_fm, "h_fake", "h_real",
+                               self.d_feat[:b], self.d_recov["mouse"][:b], recov_mouse, mouse, gm, Rm),
+                  lambda: side(dfm, fake_mouse, self.mouse_centroids, human_cat, gm, dm_adv, dm_fm, "m_fake", "m_real",
+                               self.d_feat2[:b], self.d_recov["human"][:b], recov_human, human, gh, Rh))
+        self._two(lambda: A.backward(dfh, kl=(coef, 4, 1.0)), lambda: Bp.backward(dfm, kl=(coef, 4, 1.0)))
         self.sync.launch(self.arena_g.net_grad("g_m2h"))
-        Bp.backward(dfm, kl=(coef, 4, 1.0))
         self.sync.launch(self.arena_g.net_grad("g_h2m"))
         self.sync.wait()
         self._adam(self.arena_g)

@@ -57,14 +57,29 @@ class HipOps:
         self._gemm_events = None
         # scratch shared by the kernels that need one (split-K partials, BatchNorm chunk sums); kernels on
         # one stream run in order, so one buffer per use serves every call
-        self._gemm_ws = torch.empty(8 << 20, dtype=torch.float32, device=self.device)      # 32 MiB
-        self._bn_ws = torch.empty(1 << 20, dtype=torch.float64, device=self.device)        # 8 MiB
+        # (one pair per stream, because two streams may run kernels at the same time)
+        self._scratch = {}
+
+    def _ws(self):
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        ws = self._scratch.get(key)
+        if ws is None:
+            ws = [torch.empty(8 << 20, dtype=torch.float32, device=self.device),      # 32 MiB split-K slabs
+                  torch.empty(1 << 20, dtype=torch.float64, device=self.device)]      # 8 MiB BatchNorm chunk sums
+            self._scratch[key] = ws
+        return ws
+
+    def prepare_stream(self, stream):
+        """Allocate this stream's scratch now (no allocation may happen during graph capture)."""
+        with torch.cuda.stream(stream):
+            self._ws()
 
     def _bnws(self, M, N):
+        ws = self._ws()
         need = self.lib.cg_bn_workspace_bytes(M, N)
-        if need > self._bn_ws.numel() * 8:
-            self._bn_ws = torch.empty(need // 8 + 1, dtype=torch.float64, device=self.device)
-        return C.c_void_p(self._bn_ws.data_ptr()), self._bn_ws.numel() * 8
+        if need > ws[1].numel() * 8:
+            ws[1] = torch.empty(need // 8 + 1, dtype=torch.float64, device=self.device)
+        return C.c_void_p(ws[1].data_ptr()), ws[1].numel() * 8
 
     # -- measurement: HIP events around every GEMM launch, on the launch stream ----------
     def begin_gemm_timing(self):
@@ -112,7 +127,7 @@ class HipOps:
             e0.record(torch.cuda.current_stream(self.device))
         st = self.lib.cg_gemm(_ptr(Cm), _ld(Cm), _ptr(A), _ld(A), _ptr(B), _ld(B), M, N, K, int(transA), int(transB),
                               dtype, _ptr(bias), epi, _ptr(E), _ld(E), _ptr(aux), _ld(aux), float(slope),
-                              int(accumulate), _ptr(self._gemm_ws), self._gemm_ws.numel() * 4, self._stream())
+                              int(accumulate), _ptr(self._ws()[0]), self._ws()[0].numel() * 4, self._stream())
         if self._gemm_events is not None:
             e1.record(torch.cuda.current_stream(self.device))
             self._gemm_events.append((e0, e1, 2.0 * M * N * K,

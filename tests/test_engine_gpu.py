@@ -142,9 +142,10 @@ def test_ragged_batch_smaller_than_workspace(ops):
         assert rel(g[k], e[k], FLOOR.get(k, 0.0)) <= 1e-4, (k, g[k], e[k])
 
 
-def test_graph_replay_equals_eager(ops):
+def test_graph_replay_and_two_streams_equal_eager(ops):
     """The captured critic/generator steps replay to the same parameters as launching every kernel from the host
-    (same device noise stream: torch's default generator advances identically under replay)."""
+    (same device noise stream: torch's default generator advances identically under replay), and so does running
+    the two halves of a step on two streams (any race between the halves would show as a difference)."""
     from cycle_gan_rna_amd.engine import StepEngine
     from cycle_gan_rna_amd.noise import DeviceNoise
     cfg = small_cfg(preprocess_type="log_normalized", nb_critic=2)
@@ -152,8 +153,10 @@ def test_graph_replay_equals_eager(ops):
     cm, ch = O.centroid_table(xm, lm, 12), O.centroid_table(xh, lh, 12)
     dx = [t.cuda() for t in (xm, xh, lm[:, None], lh[:, None])]
     finals = []
-    for graphs in (False, True):
+    for graphs, two_streams in ((False, False), (True, False), (False, True), (True, True)):
         eng = StepEngine(nets, cfg, cm, ch, ops, 32)
+        if two_streams:
+            eng.enable_concurrency()
         if graphs:
             eng.enable_graphs()
         noise = DeviceNoise(ops.device, seed=7, default_generator=True)
@@ -162,10 +165,11 @@ def test_graph_replay_equals_eager(ops):
             out = eng.iteration(i, *dx, noise)
         torch.cuda.synchronize()
         finals.append((eng.arena_d.p.clone(), eng.arena_g.p.clone(), out, dict(eng.nets["d_m"].nbt)))
-    (d0, g0, o0, n0), (d1, g1, o1, n1) = finals
-    assert n0 == n1
-    assert torch.equal(d0, d1) and torch.equal(g0, g1)
-    assert o0["g_loss"] == o1["g_loss"] and o0["d_m_loss"] == o1["d_m_loss"]
+    d0, g0, o0, n0 = finals[0]
+    for d1, g1, o1, n1 in finals[1:]:      # graph replay, two streams, both: bit-identical to the plain run
+        assert n0 == n1
+        assert torch.equal(d0, d1) and torch.equal(g0, g1)
+        assert o0["g_loss"] == o1["g_loss"] and o0["d_m_loss"] == o1["d_m_loss"]
 
 
 def test_bf16_mfma_path_within_stated_tolerance():
