@@ -40,8 +40,14 @@ class GradSync:
             with torch.cuda.stream(self.comm):
                 for s in range(0, flat_grad.numel(), self.bucket_elems):
                     chunk = flat_grad[s:s + self.bucket_elems]
-                    self.pending.append(dist.all_reduce(chunk, op=dist.ReduceOp.AVG, async_op=True))
-        else:   # gloo (CPU tests): no AVG
+                    # sum + scale rather than ReduceOp.AVG: identical on RCCL, and also valid on gloo, which lets
+                    # the device code path be exercised by two ranks sharing one GPU
+                    dist.all_reduce(chunk, op=dist.ReduceOp.SUM)
+                    chunk.mul_(1.0 / self.world)
+            done = torch.cuda.Event()
+            done.record(self.comm)
+            self.pending.append(done)
+        else:   # CPU tensors (gloo tests)
             for s in range(0, flat_grad.numel(), self.bucket_elems):
                 chunk = flat_grad[s:s + self.bucket_elems]
                 dist.all_reduce(chunk, op=dist.ReduceOp.SUM)
@@ -49,8 +55,8 @@ class GradSync:
 
     def wait(self):
         """Make the current stream wait for every launched bucket."""
-        for w in self.pending:
-            w.wait()
+        for ev in self.pending:
+            torch.cuda.current_stream(self.device).wait_event(ev)
         self.pending = []
 
     def sum_scalars(self, t):

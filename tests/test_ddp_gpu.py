@@ -1,0 +1,51 @@
+"""The device code path of the data-parallel step (side comm stream, events, scalar sync) with two ranks that
+share the one GPU of the test box.  RCCL refuses two ranks on one device, so the ranks talk over gloo; the engine
+code is the same as under RCCL (sum + scale on a side stream, then the fused Adam)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from cycle_gan_rna_amd.engine import StepEngine
+    from cycle_gan_rna_amd.noise import DeviceNoise
+    from cycle_gan_rna_amd.ops import HipOps
+    from oracle import cyclegan_oracle as O
+    from tests.helpers import make_problem, small_cfg
+    cfg = small_cfg(preprocess_type="log_normalized", nb_critic=1)
+    nets, xm, xh, lm, lh = make_problem(64, 64, 32, cfg)
+    cm, ch = O.centroid_table(xm, lm, 12), O.centroid_table(xh, lh, 12)
+    b = 16
+    sl = slice(rank * b, (rank + 1) * b)
+    eng = StepEngine(nets, cfg, cm, ch, HipOps("cuda:0"), b)
+    eng.enable_concurrency()
+    assert eng.sync.enabled
+    noise = DeviceNoise("cuda:0", seed=5 + rank, default_generator=True)
+    for i in range(2):
+        noise.begin_step()
+        res = eng.iteration(i, xm[sl].cuda(), xh[sl].cuda(), lm[sl, None].cuda(), lh[sl, None].cuda(), noise)
+    torch.cuda.synchronize()
+    torch.save(dict(d=eng.arena_d.p.cpu(), g=eng.arena_g.p.cpu(), coef=eng.coef.cpu(), g_loss=res["g_loss"]),
+               os.path.join(out, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_stay_identical(tmp_path):
+    world, port = 2, 29600 + os.getpid() % 2000
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(tmp_path / "rank0.pt", weights_only=True)
+    r1 = torch.load(tmp_path / "rank1.pt", weights_only=True)
+    assert torch.isfinite(r0["d"]).all() and torch.isfinite(r0["g"]).all()
+    assert torch.equal(r0["d"], r1["d"]) and torch.equal(r0["g"], r1["g"]), "ranks diverged"
+    assert torch.equal(r0["coef"], r1["coef"])
