@@ -119,7 +119,7 @@ def main():
     noise = DeviceNoise(dev, seed=1 + rank, default_generator=True)
     if not a.sequential:
         eng.enable_concurrency()
-    if not a.eager and world == 1:
+    if not a.eager:
         eng.enable_graphs()
 
     def step(i):
@@ -159,6 +159,7 @@ def main():
         # and each bracketed by HIP events on the launch stream.  A block of filler work is queued first so that the
         # host runs ahead of the GPU and the event pairs time the kernels, not the gaps between launches.
         eng.use_graphs = False
+        eng.concurrent = False         # one stream: every launch is timed with the chip to itself
         filler_a = torch.rand(4096, 4096, device=dev)
         filler_c = torch.empty(4096, 4096, device=dev)
         ops.begin_gemm_timing()

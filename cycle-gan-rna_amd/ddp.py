@@ -27,12 +27,18 @@ class GradSync:
         self.bucket_elems = bucket_bytes // 4
         self.comm = torch.cuda.Stream(device=self.device) if (self.enabled and self.is_cuda) else None
         self.pending = []
+        # The gloo backend stages device tensors through the host on a helper thread; issued right behind a HIP
+        # graph replay that staging never completes on this stack, so gloo (CPU clusters and tests; RCCL is the
+        # production backend) gets a host synchronisation before every collective.
+        self.host_sync = self.enabled and self.is_cuda and dist.get_backend() == "gloo"
 
     def launch(self, flat_grad):
         """Start averaging `flat_grad` (a contiguous 1-D view whose producer kernels
         have been enqueued on the current stream)."""
         if not self.enabled:
             return
+        if self.host_sync:
+            torch.cuda.synchronize(self.device)
         if self.is_cuda:
             ready = torch.cuda.Event()
             ready.record(torch.cuda.current_stream(self.device))
@@ -61,6 +67,8 @@ class GradSync:
 
     def sum_scalars(self, t):
         """Sum a small tensor over ranks, in place, on the current stream."""
+        if self.host_sync:
+            torch.cuda.synchronize(self.device)
         if self.enabled:
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return t

@@ -599,7 +599,8 @@ class StepEngine:
         """Capture the device work of the critic step and of the generator step into HIP
         graphs (first full-size call runs eagerly, the second is captured, later ones are
         replayed).  Needs a noise source that draws into fixed device buffers
-        (noise.DeviceNoise); ragged batches and multi-rank runs stay eager."""
+        (noise.DeviceNoise); ragged batches stay eager.  With several ranks the collectives stay outside the
+        graphs (see _run_parts)."""
         self._graphs = {}
         self.use_graphs = True
 
@@ -616,7 +617,9 @@ class StepEngine:
         if st["graph"] is None:
             before = {n: dict(net.nbt) for n, net in self.nets.items()}
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread-local capture mode: helper threads of the process (a collective backend's progress thread, for
+            # one) may keep making HIP calls while this thread captures
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 body(*st["static"], noise)
             st["graph"] = g
             st["nbt"] = {n: {k: net.nbt[k] - before[n][k] for k in net.nbt} for n, net in self.nets.items()}
@@ -637,12 +640,37 @@ class StepEngine:
             lam = float(self.cfg["lambda_gp"])
             self.d_scales.copy_(torch.tensor([-1.0 / b, 1.0 / b, lam / b] * 2, dtype=torch.float64))
             self._d_scales_b = b
-        if self.use_graphs and b == self.max_b and not self.sync.enabled:
-            self._graphed("d", self._d_body, (mouse, human, mouse_cat, human_cat), noise)
-        else:
-            self._d_body(mouse, human, mouse_cat, human_cat, noise)
+        self._run_parts("d", b, (mouse, human, mouse_cat, human_cat), noise,
+                        [self._d_compute, self._d_comm, self._d_update])
 
-    def _d_body(self, mouse, human, mouse_cat, human_cat, noise):
+    def _run_parts(self, kind, b, tensors, noise, parts):
+        """A step is a list of parts: device work, a collective, device work, ...  On one rank the collectives are
+        no-ops and the whole list is one HIP graph; with several ranks every device part is a graph of its own and
+        the collectives between them are issued eagerly."""
+        first, rest = parts[0], parts[1:]
+        graphs = self.use_graphs and b == self.max_b
+
+        def whole(*a):
+            first(*a)
+            for fn in rest:
+                fn()
+        if not self.sync.enabled:
+            if graphs:
+                self._graphed(kind, whole, tensors, noise)
+            else:
+                whole(*tensors, noise)
+            return
+        for i, fn in enumerate(parts):
+            if i % 2 == 1:
+                fn()                                       # collective
+            elif not graphs:
+                fn(*tensors, noise) if i == 0 else fn()
+            elif i == 0:
+                self._graphed(f"{kind}{i}", fn, tensors, noise)
+            else:
+                self._graphed(f"{kind}{i}", lambda _noise, fn=fn: fn(), (), noise)
+
+    def _d_compute(self, mouse, human, mouse_cat, human_cat, noise):
         ops, cfg = self.ops, self.cfg
         b = mouse.shape[0]
         self.arena_d.g.zero_()
@@ -668,11 +696,14 @@ class StepEngine:
             dp.gp_backward(cfg["lambda_gp"], self.red, s0 + 2)
         self._two(lambda: critic("d_m", mouse, mouse_cat, fake_mouse, human_cat, S_DM_REAL),
                   lambda: critic("d_h", human, human_cat, fake_human, mouse_cat, S_DH_REAL))
-        self.sync.launch(self.arena_d.net_grad("d_m"))
-        self.sync.launch(self.arena_d.net_grad("d_h"))
+
+    def _d_comm(self):
+        self.sync.launch(self.arena_d.g)
         self.sync.wait()
+
+    def _d_update(self):
         self._adam(self.arena_d)
-        ops.sum_parts(self.d_tot, self.red, self.d_slots, self.d_scales)
+        self.ops.sum_parts(self.d_tot, self.red, self.d_slots, self.d_scales)
 
     def d_losses(self):
         t = self.d_tot.cpu()
@@ -685,12 +716,10 @@ class StepEngine:
     def g_step(self, mouse, human, mouse_cat, human_cat, noise):
         b = mouse.shape[0]
         self._begin_opt(self.arena_g, self.lr_g)
-        if self.use_graphs and b == self.max_b and not self.sync.enabled:
-            self._graphed("g", self._g_body, (mouse, human, mouse_cat, human_cat), noise)
-        else:
-            self._g_body(mouse, human, mouse_cat, human_cat, noise)
+        self._run_parts("g", b, (mouse, human, mouse_cat, human_cat), noise,
+                        [self._g_forward, self._g_loss_comm, self._g_backward, self._g_grad_comm, self._g_update])
 
-    def _g_body(self, mouse, human, mouse_cat, human_cat, noise):
+    def _g_forward(self, mouse, human, mouse_cat, human_cat, noise):
         ops, cfg = self.ops, self.cfg
         b = mouse.shape[0]
         gm, gh = self.g_mouse, self.g_human
@@ -733,11 +762,26 @@ class StepEngine:
                                 "h_real", "h_fake", S_FM_H, A, S_KL_H),
                   lambda: ct_fm(fake_mouse, self.mouse_centroids, human_cat, S_CT_M, dm_tmp, dm_fm, mouse, mouse_cat,
                                 "m_real", "m_fake", S_FM_M, Bp, S_KL_M))
+        if self.sync.enabled:
+            ops.sum_parts(self.g_tot, red, self.g_slots, self.g_ones)
+        self._g_state = (mouse, human, mouse_cat, human_cat, o)
+
+    def _g_loss_comm(self):
+        # every rank must derive the same loss scales: the local loss sums are replaced by their sum over ranks
+        self.sync.sum_scalars(self.g_tot)
+
+    def _g_backward(self):
+        ops, cfg, red = self.ops, self.cfg, self.red
+        mouse, human, mouse_cat, human_cat, o = self._g_state
+        fake_human, fake_mouse, recov_mouse, recov_human = o["fh"], o["fm"], o["rm"], o["rh"]
+        b = mouse.shape[0]
+        gm, gh = self.g_mouse, self.g_human
+        A, Bp = self.gen_a["g_m2h"], self.gen_a["g_h2m"]
+        Rm, Rh = self.gen_b["g_h2m"], self.gen_b["g_m2h"]
+        dh_adv, dh_fm, _ = self.disc["d_h"]
+        dm_adv, dm_fm, _ = self.disc["d_m"]
         L = cfg["latent_dim"]
         if self.sync.enabled:
-            # every rank must derive the same loss scales: replace the local loss sums by their sum over ranks
-            ops.sum_parts(self.g_tot, red, self.g_slots, self.g_ones)
-            self.sync.sum_scalars(self.g_tot)
             red[0][S_ADV_H:S_ADV_H + 10, 0] = self.g_tot.to(red[0].dtype)
             red[1][S_ADV_H:S_ADV_H + 10] = 1
         bl = b
@@ -770,9 +814,15 @@ class StepEngine:
                   lambda: side(dfm, fake_mouse, self.mouse_centroids, human_cat, gm, dm_adv, dm_fm, "m_fake", "m_real",
                                self.d_feat2[:b], self.d_recov["human"][:b], recov_human, human, gh, Rh))
         self._two(lambda: A.backward(dfh, kl=(coef, 4, 1.0)), lambda: Bp.backward(dfm, kl=(coef, 4, 1.0)))
-        self.sync.launch(self.arena_g.net_grad("g_m2h"))
-        self.sync.launch(self.arena_g.net_grad("g_h2m"))
+
+    def _g_grad_comm(self):
+        self.sync.launch(self.arena_g.g)
         self.sync.wait()
+
+    def _g_update(self):
+        ops = self.ops
+        o = self._g_state[4]
+        fake_human, fake_mouse = o["fh"], o["fm"]
         self._adam(self.arena_g)
         ops.colvar_mean(self.var_out[0:1], self.var_ws, fake_human)        # :418-419
         ops.colvar_mean(self.var_out[1:2], self.var_ws, fake_mouse)

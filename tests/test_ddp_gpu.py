@@ -13,7 +13,9 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, graphs):
+    import faulthandler
+    faulthandler.dump_traceback_later(60, exit=True)      # a hung rank reports where, then exits
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -30,22 +32,29 @@ def _worker(rank, world, port, out):
     sl = slice(rank * b, (rank + 1) * b)
     eng = StepEngine(nets, cfg, cm, ch, HipOps("cuda:0"), b)
     eng.enable_concurrency()
+    if graphs:
+        eng.enable_graphs()
     assert eng.sync.enabled
     noise = DeviceNoise("cuda:0", seed=5 + rank, default_generator=True)
-    for i in range(2):
+    for i in range(5):
         noise.begin_step()
         res = eng.iteration(i, xm[sl].cuda(), xh[sl].cuda(), lm[sl, None].cuda(), lh[sl, None].cuda(), noise)
+    assert not graphs or all(g["graph"] is not None for g in eng._graphs.values())
     torch.cuda.synchronize()
     torch.save(dict(d=eng.arena_d.p.cpu(), g=eng.arena_g.p.cpu(), coef=eng.coef.cpu(), g_loss=res["g_loss"]),
-               os.path.join(out, f"rank{rank}.pt"))
+               os.path.join(out, f"rank{rank}_{int(graphs)}.pt"))
     dist.destroy_process_group()
 
 
 def test_two_ranks_on_one_gpu_stay_identical(tmp_path):
     world, port = 2, 29600 + os.getpid() % 2000
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
-    r0 = torch.load(tmp_path / "rank0.pt", weights_only=True)
-    r1 = torch.load(tmp_path / "rank1.pt", weights_only=True)
-    assert torch.isfinite(r0["d"]).all() and torch.isfinite(r0["g"]).all()
-    assert torch.equal(r0["d"], r1["d"]) and torch.equal(r0["g"], r1["g"]), "ranks diverged"
-    assert torch.equal(r0["coef"], r1["coef"])
+    res = {}
+    for graphs in (False, True):        # eager, then every device part of a step as a HIP graph with eager collectives
+        mp.spawn(_worker, args=(world, port + int(graphs), str(tmp_path), graphs), nprocs=world, join=True)
+        r0 = torch.load(tmp_path / f"rank0_{int(graphs)}.pt", weights_only=True)
+        r1 = torch.load(tmp_path / f"rank1_{int(graphs)}.pt", weights_only=True)
+        assert torch.isfinite(r0["d"]).all() and torch.isfinite(r0["g"]).all()
+        assert torch.equal(r0["d"], r1["d"]) and torch.equal(r0["g"], r1["g"]), "ranks diverged"
+        assert torch.equal(r0["coef"], r1["coef"])
+        res[graphs] = r0
+    assert torch.equal(res[False]["d"], res[True]["d"]) and torch.equal(res[False]["g"], res[True]["g"])
