@@ -88,6 +88,7 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32: exact float32 MFMA everywhere; bf16: large dense-layer products on the bf16 MFMA")
     ap.add_argument("--sequential", action="store_true", help="one stream instead of two")
+    ap.add_argument("--gemm-shapes", action="store_true", help="print the per-shape GEMM time table to stderr")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying HIP graphs")
     a = ap.parse_args()
 
@@ -169,6 +170,15 @@ def main():
             step(i)
         torch.cuda.synchronize()
         n_launch, gemm_ms, exec_flop, gemm_bytes = ops.end_gemm_timing()
+        if a.gemm_shapes:
+            agg = {}
+            for shape, ms, fl in ops.last_gemm_detail:
+                c = agg.setdefault(shape, [0, 0.0, 0.0])
+                c[0] += 1; c[1] += ms; c[2] += fl
+            print("   M     N     K tA tB acc dt |  n/it   us/launch   ms/it   TF/s", file=sys.stderr)
+            for shape, (n, ms, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                print("%5d %5d %5d %2d %2d %3d %2d | %5.1f %10.1f %7.3f %6.1f" % (*shape, n / NB_CRITIC, ms / n * 1e3,
+                      ms / NB_CRITIC, fl / ms / 1e9), file=sys.stderr)
         # HBM bytes per GEMM launch measured with rocprofv3 PMC passes of this same workload (tools/pmc_summary.py);
         # the summary is committed under profiles/ because counters cannot be collected from inside this process
         traffic = None

@@ -74,12 +74,14 @@ __device__ __forceinline__ void get_totals(double (&s)[NS], double* lds, const d
   strip_reduce<NS>(s, lds);
 }
 
+// M is the number of rows of one segment; segment blockIdx.z owns rows [z*M, (z+1)*M) and its own statistics.
 #define BN_COMMON                                              \
   const int c = threadIdx.x & (CW - 1), r0 = threadIdx.x / CW; \
   const int col = blockIdx.x * CW + c;                         \
   const bool ok = col < N;                                     \
-  const int m0 = blockIdx.y * rows;                            \
-  const int m1 = min(M, m0 + rows);
+  const int seg = blockIdx.z;                                  \
+  const int m0 = seg * M + blockIdx.y * rows;                  \
+  const int m1 = min((seg + 1) * M, m0 + rows);
 
 __device__ __forceinline__ float pm_of(const float* Y, int ldy, const float* PM, int ldpm, float slope, int m, int col) {
   if (PM) return PM[(size_t)m * ldpm + col];
@@ -98,18 +100,37 @@ __global__ void __launch_bounds__(256) bn_fwd_stats(double* ws, const float* X, 
       s[0] += x;
       s[1] += x * x;
     }
-  put_partials<2>(s, lds, ws, N, col);
+  put_partials<2>(s, lds, ws + (size_t)seg * 2 * gridDim.y * N, N, col);
 }
 
 __global__ void __launch_bounds__(256) bn_fwd_apply(const double* ws, float* Y, int ldy, const float* X, int ldx, int M,
                                                     int N, int rows, const float* gamma, const float* beta, float eps,
                                                     float* mean_out, float* invstd_out, float* rmean, float* rvar,
                                                     float momentum, float slope, const float* mask, int ldmask,
-                                                    float* pm_out, int ldpm, u16* ybf, int ldybf) {
+                                                    float* pm_out, int ldpm, u16* ybf, int ldybf, unsigned order) {
   __shared__ double lds[2 * RL * CW];
   BN_COMMON
+  const size_t seg_ws = (size_t)2 * gridDim.y * N;
   double s[2];
-  get_totals<2>(s, lds, ws, N, col);
+  if (blockIdx.y == 0 && seg == 0 && (rmean || rvar)) {
+    // running statistics: one update per segment, applied in the caller's order (the order in which the
+    // reference would have made the separate calls); 4 bits of `order` per position
+    for (int k = 0; k < (int)gridDim.z; ++k) {
+      const int sg = (order >> (4 * k)) & 15;
+      get_totals<2>(s, lds, ws + sg * seg_ws, N, col);
+      if (ok && r0 == 0) {
+        const double mean_d = s[0] / M;
+        double var_d = s[1] / M - mean_d * mean_d;
+        if (var_d < 0.0) var_d = 0.0;
+        if (rmean) rmean[col] = (1.f - momentum) * rmean[col] + momentum * (float)mean_d;
+        if (rvar) {
+          const float unb = (float)(var_d * ((double)M / (double)(M > 1 ? M - 1 : 1)));
+          rvar[col] = (1.f - momentum) * rvar[col] + momentum * unb;
+        }
+      }
+    }
+  }
+  get_totals<2>(s, lds, ws + seg * seg_ws, N, col);
   if (!ok) return;
   const double mean_d = s[0] / M;
   double var_d = s[1] / M - mean_d * mean_d;
@@ -117,13 +138,8 @@ __global__ void __launch_bounds__(256) bn_fwd_apply(const double* ws, float* Y, 
   const float mean = (float)mean_d;
   const float invstd = (float)(1.0 / sqrt(var_d + (double)eps));
   if (blockIdx.y == 0 && r0 == 0) {
-    mean_out[col] = mean;
-    invstd_out[col] = invstd;
-    if (rmean) rmean[col] = (1.f - momentum) * rmean[col] + momentum * mean;
-    if (rvar) {
-      const float unb = (float)(var_d * ((double)M / (double)(M > 1 ? M - 1 : 1)));
-      rvar[col] = (1.f - momentum) * rvar[col] + momentum * unb;
-    }
+    mean_out[(size_t)seg * N + col] = mean;
+    invstd_out[(size_t)seg * N + col] = invstd;
   }
   const float ga = gamma[col], be = beta[col];
   for (int m = m0 + r0; m < m1; m += RL) {
@@ -158,7 +174,7 @@ __global__ void __launch_bounds__(256) bn_bwd_stats(double* ws, const float* dY,
                                                     int rows) {
   __shared__ double lds[2 * RL * CW];
   BN_COMMON
-  const float mu = ok ? mean[col] : 0.f, is = ok ? invstd[col] : 0.f;
+  const float mu = ok ? mean[(size_t)seg * N + col] : 0.f, is = ok ? invstd[(size_t)seg * N + col] : 0.f;
   double s[2] = {0.0, 0.0};
   if (ok)
     for (int m = m0 + r0; m < m1; m += RL) {
@@ -167,7 +183,7 @@ __global__ void __launch_bounds__(256) bn_bwd_stats(double* ws, const float* dY,
       s[0] += g;
       s[1] += (double)g * xh;
     }
-  put_partials<2>(s, lds, ws, N, col);
+  put_partials<2>(s, lds, ws + (size_t)seg * 2 * gridDim.y * N, N, col);
 }
 
 __global__ void __launch_bounds__(256) bn_bwd_apply(const double* ws, float* dX, int lddx, const float* dY, int lddy,
@@ -178,16 +194,28 @@ __global__ void __launch_bounds__(256) bn_bwd_apply(const double* ws, float* dX,
                                                     int rows) {
   __shared__ double lds[2 * RL * CW];
   BN_COMMON
+  const size_t seg_ws = (size_t)2 * gridDim.y * N;
   double s[2];
-  get_totals<2>(s, lds, ws, N, col);
+  if (blockIdx.y == 0 && seg == 0 && (dbeta || dgamma)) {
+    // parameter gradients sum over all segments, added in segment order as separate calls would
+    float db = (ok && dbeta && accumulate) ? dbeta[col] : 0.f, dg = (ok && dgamma && accumulate) ? dgamma[col] : 0.f;
+    for (int sg = 0; sg < (int)gridDim.z; ++sg) {
+      get_totals<2>(s, lds, ws + sg * seg_ws, N, col);
+      db += (float)s[0];
+      dg += (float)s[1];
+    }
+    if (ok && r0 == 0) {
+      if (dbeta) dbeta[col] = db;
+      if (dgamma) dgamma[col] = dg;
+    }
+  }
+  get_totals<2>(s, lds, ws + seg * seg_ws, N, col);
   if (!ok) return;
-  const float mu = mean[col], is = invstd[col];
+  const float mu = mean[(size_t)seg * N + col], is = invstd[(size_t)seg * N + col];
   const float gbar = (float)(s[0] / M), gxbar = (float)(s[1] / M);
   if (blockIdx.y == 0 && r0 == 0) {
-    if (dbeta) dbeta[col] = (accumulate ? dbeta[col] : 0.f) + (float)s[0];
-    if (dgamma) dgamma[col] = (accumulate ? dgamma[col] : 0.f) + (float)s[1];
-    if (gbar_out) gbar_out[col] = gbar;
-    if (gxbar_out) gxbar_out[col] = gxbar;
+    if (gbar_out) gbar_out[(size_t)seg * N + col] = gbar;
+    if (gxbar_out) gxbar_out[(size_t)seg * N + col] = gxbar;
   }
   const float k = is * gamma[col];
   for (int m = m0 + r0; m < m1; m += RL) {
@@ -251,21 +279,35 @@ extern "C" size_t cg_bn_workspace_bytes(int M, int N) {
   return (size_t)3 * g.rc * N * sizeof(double);
 }
 
+extern "C" int cg_bn_fwd_seg(float* Y, int ldy, const float* X, int ldx, int seg_rows, int nseg, unsigned order, int N,
+                             const float* gamma, const float* beta, float eps, float* mean_out, float* invstd_out,
+                             float* running_mean, float* running_var, float momentum, float slope, const float* mask,
+                             int ldmask, float* pm_out, int ldpm, void* ybf16, int ldybf16, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+  const int M = seg_rows;
+  if (!Y || !X || !gamma || !beta || !mean_out || !invstd_out || M <= 0 || N <= 0) return CG_ERR_BAD_ARG;
+  if (nseg < 1 || nseg > 8) return CG_ERR_BAD_ARG;
+  unsigned seen = 0;
+  for (int k = 0; k < nseg; ++k) seen |= 1u << ((order >> (4 * k)) & 15);
+  if (seen != (1u << nseg) - 1) return CG_ERR_BAD_ARG;          // `order` must be a permutation of 0..nseg-1
+  if (ldy < N || ldx < N || (mask && ldmask < N) || (pm_out && ldpm < N) || (ybf16 && ldybf16 < N)) return CG_ERR_BAD_ARG;
+  if (!workspace || workspace_bytes < nseg * cg_bn_workspace_bytes(M, N)) return CG_ERR_WORKSPACE;
+  const Geo g = geo(M, N);
+  dim3 grid(g.strips, g.rc, nseg);
+  hipLaunchKernelGGL(bn_fwd_stats, grid, dim3(256), 0, (hipStream_t)stream, (double*)workspace, X, ldx, M, N, g.rows);
+  hipLaunchKernelGGL(bn_fwd_apply, grid, dim3(256), 0, (hipStream_t)stream, (const double*)workspace, Y, ldy, X, ldx,
+                     M, N, g.rows, gamma, beta, eps, mean_out, invstd_out, running_mean, running_var, momentum, slope,
+                     mask, ldmask, pm_out, ldpm, (u16*)ybf16, ldybf16, order);
+  return cg_launch_status();
+}
+
 extern "C" int cg_bn_fwd(float* Y, int ldy, const float* X, int ldx, int M, int N, const float* gamma,
                          const float* beta, float eps, float* mean_out, float* invstd_out, float* running_mean,
                          float* running_var, float momentum, float slope, const float* mask, int ldmask,
                          float* pm_out, int ldpm, void* ybf16, int ldybf16, void* workspace, size_t workspace_bytes,
                          void* stream) {
-  if (!Y || !X || !gamma || !beta || !mean_out || !invstd_out || M <= 0 || N <= 0) return CG_ERR_BAD_ARG;
-  if (ldy < N || ldx < N || (mask && ldmask < N) || (pm_out && ldpm < N) || (ybf16 && ldybf16 < N)) return CG_ERR_BAD_ARG;
-  if (!workspace || workspace_bytes < cg_bn_workspace_bytes(M, N)) return CG_ERR_WORKSPACE;
-  const Geo g = geo(M, N);
-  dim3 grid(g.strips, g.rc);
-  hipLaunchKernelGGL(bn_fwd_stats, grid, dim3(256), 0, (hipStream_t)stream, (double*)workspace, X, ldx, M, N, g.rows);
-  hipLaunchKernelGGL(bn_fwd_apply, grid, dim3(256), 0, (hipStream_t)stream, (const double*)workspace, Y, ldy, X, ldx,
-                     M, N, g.rows, gamma, beta, eps, mean_out, invstd_out, running_mean, running_var, momentum, slope,
-                     mask, ldmask, pm_out, ldpm, (u16*)ybf16, ldybf16);
-  return cg_launch_status();
+  return cg_bn_fwd_seg(Y, ldy, X, ldx, M, 1, 0u, N, gamma, beta, eps, mean_out, invstd_out, running_mean, running_var,
+                       momentum, slope, mask, ldmask, pm_out, ldpm, ybf16, ldybf16, workspace, workspace_bytes, stream);
 }
 
 extern "C" int cg_bn_eval(float* Y, int ldy, const float* X, int ldx, int M, int N, const float* gamma,
@@ -285,11 +327,21 @@ extern "C" int cg_bn_bwd(float* dX, int lddx, const float* dY, int lddy, const f
                          const float* gamma, float* dgamma, float* dbeta, int accumulate, float* gbar_out,
                          float* gxbar_out, float slope, int M, int N, void* workspace, size_t workspace_bytes,
                          void* stream) {
-  if (!dX || !dY || !X || !mean || !invstd || !gamma || M <= 0 || N <= 0) return CG_ERR_BAD_ARG;
+  return cg_bn_bwd_seg(dX, lddx, dY, lddy, X, ldx, Y, ldy, PM, ldpm, mean, invstd, gamma, dgamma, dbeta, accumulate,
+                       gbar_out, gxbar_out, slope, M, 1, N, workspace, workspace_bytes, stream);
+}
+
+extern "C" int cg_bn_bwd_seg(float* dX, int lddx, const float* dY, int lddy, const float* X, int ldx, const float* Y,
+                             int ldy, const float* PM, int ldpm, const float* mean, const float* invstd,
+                             const float* gamma, float* dgamma, float* dbeta, int accumulate, float* gbar_out,
+                             float* gxbar_out, float slope, int seg_rows, int nseg, int N, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+  const int M = seg_rows;
+  if (!dX || !dY || !X || !mean || !invstd || !gamma || M <= 0 || N <= 0 || nseg < 1 || nseg > 8) return CG_ERR_BAD_ARG;
   if (lddx < N || lddy < N || ldx < N || (Y && ldy < N) || (PM && ldpm < N)) return CG_ERR_BAD_ARG;
-  if (!workspace || workspace_bytes < cg_bn_workspace_bytes(M, N)) return CG_ERR_WORKSPACE;
+  if (!workspace || workspace_bytes < nseg * cg_bn_workspace_bytes(M, N)) return CG_ERR_WORKSPACE;
   const Geo g = geo(M, N);
-  dim3 grid(g.strips, g.rc);
+  dim3 grid(g.strips, g.rc, nseg);
   hipLaunchKernelGGL(bn_bwd_stats, grid, dim3(256), 0, (hipStream_t)stream, (double*)workspace, dY, lddy, X, ldx, Y,
                      ldy, PM, ldpm, mean, invstd, slope, M, N, g.rows);
   hipLaunchKernelGGL(bn_bwd_apply, grid, dim3(256), 0, (hipStream_t)stream, (const double*)workspace, dX, lddx, dY,

@@ -486,6 +486,178 @@ class DiscPass:
             ops.embed_scatter(G["embeddings.0.weight"], self.demb[:b], self.labels, True)
 
 
+class CriticStack:
+    """Several calls of one critic evaluated at once.  The reference calls a critic on the real, the generated and
+    the interpolated batch one after the other (GAN_functions.py:326-336), and three times per species in the
+    generator step (:347, :366-371).  Here the batches are stacked along the rows ("segments"): every linear layer
+    runs once over all rows, BatchNorm normalises each segment with its own statistics and updates the running
+    statistics once per segment in the reference's call order, dropout masks are per row anyway.
+
+    nseg: segments of the hidden activations; nx: distinct input batches.  With nx < nseg the first input feeds
+    segments 0..nseg-nx (the generator step looks at the same generated batch twice), the others one segment each.
+    Segments are packed at stride b (the current batch size), so ragged batches stay contiguous."""
+
+    def __init__(self, engine, net: Net, in_dim, max_b, nseg, nx):
+        ops = engine.ops
+        self.e, self.ops, self.net = engine, ops, net
+        self.Gd, self.E, self.S, self.nx = in_dim, engine.emb_dim, nseg, nx
+        Z, B, S = ops.zeros, max_b, nseg
+        self.x = Z(nx * B, in_dim)
+        self.lab = ops.to_device(torch.zeros(nx * B, 1, dtype=torch.int64))
+        self.emb = Z(nx * B, self.E)
+        self.h0, self.a1, self.pm1 = Z(S * B, 1024), Z(S * B, 1024), Z(S * B, 1024)
+        self.stats = (Z(S, 1024), Z(S, 1024))
+        self.a2, self.pm2 = Z(S * B, 512), Z(S * B, 512)
+        self.a3, self.pm3 = Z(S * B, 256), Z(S * B, 256)
+        self.val = Z(S * B, 1)
+        self.dval = Z(S * B, 1)
+        self._dval_b = None
+        self.ones = ops.to_device(torch.ones(B, 1))
+        self.g256, self.g512, self.g1024a, self.g1024b = Z(S * B, 256), Z(S * B, 512), Z(S * B, 1024), Z(S * B, 1024)
+        self.h256, self.h512, self.h1024a, self.h1024b = Z(B, 256), Z(B, 512), Z(B, 1024), Z(B, 1024)
+        self.dsum = Z(B, 1024)
+        self.demb = Z(nx * B, self.E)
+        self.ux = Z(B, in_dim)
+        self.rowpen = Z(B)
+        self.ubar, self.mbar = Z(1024), Z(1024)
+        self.b, self.have_labels = 0, True
+
+    def x_seg(self, i, b):
+        return self.x[i * b:(i + 1) * b]
+
+    def load(self, i, b, x, labels):
+        """Input batch i (x may be None when the rows were written in place through x_seg)."""
+        if x is not None:
+            self.x[i * b:(i + 1) * b].copy_(x)
+        self.have_labels = labels is not None
+        if labels is not None:
+            self.lab[i * b:(i + 1) * b].copy_(labels)
+
+    def forward(self, b, m1, m2, order):
+        """m1 (nseg*b, 1024), m2 (nseg*b, 512): dropout keep masks.  Returns validity (nseg*b, 1) and the features
+        (nseg*b, 256), segment-major."""
+        ops, P, Bf, Gd, S, nx = self.ops, self.net.P, self.net.B, self.Gd, self.S, self.nx
+        self.b = b
+        R, Rx, off = S * b, nx * b, (S - nx) * b
+        W1 = P["model.0.weight"]
+        x, emb = self.x[:Rx], self.emb[:Rx]
+        if self.have_labels:
+            ops.embed_gather(emb, P["embeddings.0.weight"], self.lab[:Rx])
+        else:
+            emb.zero_()
+        h0 = self.h0[:R]
+        ops.gemm(h0[off:], x, W1[:, :Gd], False, True, bias=P["model.0.bias"])
+        ops.gemm(h0[off:], emb, W1[:, Gd:], False, True, accumulate=True)
+        for k in range(S - nx):
+            h0[k * b:(k + 1) * b].copy_(h0[off:off + b])
+        ops.bn_fwd_seg(self.a1[:R], h0, S, order, P["model.1.weight"], P["model.1.bias"], self.stats[0], self.stats[1],
+                       Bf["model.1.running_mean"], Bf["model.1.running_var"], 0.2, m1, self.pm1[:R])
+        self.net.nbt["model.1.num_batches_tracked"] += S
+        ops.gemm(self.a2[:R], self.a1[:R], P["model.4.weight"], False, True, bias=P["model.4.bias"], epi=EPI_LEAKY,
+                 E=m2, aux=self.pm2[:R], slope=0.2)
+        ops.gemm(self.a3[:R], self.a2[:R], P["model.7.weight"], False, True, bias=P["model.7.bias"], epi=EPI_LEAKY,
+                 E=None, aux=self.pm3[:R], slope=0.2)
+        ops.gemm(self.val[:R], self.a3[:R], P["model.9.weight"], False, True, bias=P["model.9.bias"])
+        return self.val[:R], self.a3[:R]
+
+    def backward_params(self, b, scales):
+        """Critic step: parameter gradients of  sum_s scales[s] * sum(validity of segment s)  over the first
+        len(scales) segments (needs nx == nseg), accumulated into the gradient arena."""
+        ops, P, G, Gd = self.ops, self.net.P, self.net.G, self.Gd
+        assert self.nx == self.S
+        ns = len(scales)
+        R = ns * b
+        if self._dval_b != (b, tuple(scales)):
+            self.dval[:R].copy_(ops.to_device(torch.tensor(scales, dtype=torch.float32).repeat_interleave(b)[:, None]))
+            self._dval_b = (b, tuple(scales))
+        W1 = P["model.0.weight"]
+        dval, dh3 = self.dval[:R], self.g256[:R]
+        ops.gemm(G["model.9.weight"], dval, self.a3[:R], True, False, accumulate=True)
+        ops.colsum(G["model.9.bias"], dval, 1.0, True)
+        ops.gemm(dh3, dval, P["model.9.weight"], False, False, epi=EPI_MUL, E=self.pm3[:R])
+        ops.gemm(G["model.7.weight"], dh3, self.a2[:R], True, False, accumulate=True)
+        ops.colsum(G["model.7.bias"], dh3, 1.0, True)
+        dh2 = self.g512[:R]
+        ops.gemm(dh2, dh3, P["model.7.weight"], False, False, epi=EPI_MUL, E=self.pm2[:R])
+        ops.gemm(G["model.4.weight"], dh2, self.a1[:R], True, False, accumulate=True)
+        ops.colsum(G["model.4.bias"], dh2, 1.0, True)
+        da1 = self.g1024a[:R]
+        ops.gemm(da1, dh2, P["model.4.weight"], False, False)
+        dh0 = self.g1024b[:R]
+        ops.bn_bwd_seg(dh0, da1, self.h0[:R], None, self.pm1[:R], ns, self.stats[0], self.stats[1], P["model.1.weight"],
+                       G["model.1.weight"], G["model.1.bias"], True, 0.2)
+        gW1 = G["model.0.weight"]
+        ops.gemm(gW1[:, :Gd], dh0, self.x[:R], True, False, accumulate=True)
+        ops.gemm(gW1[:, Gd:], dh0, self.emb[:R], True, False, accumulate=True)
+        if self.have_labels:
+            ops.gemm(self.demb[:R], dh0, W1[:, Gd:], False, False)
+            ops.embed_scatter(G["embeddings.0.weight"], self.demb[:R], self.lab[:R], True)
+
+    def backward_input(self, b, coef, idx, scale, dfeat, dx_out):
+        """Generator step (nx = nseg - 1): gradient w.r.t. the first input batch of
+        coef[idx]*scale*sum(validity of segment 0) + <dfeat, features of segment 1>, accumulated into dx_out.
+        Both segments look at the same input, so their first-layer gradients are added before the one
+        product with W1."""
+        ops, P, Gd = self.ops, self.net.P, self.Gd
+        assert self.S - self.nx == 1
+        R = 2 * b
+        dval, dh3 = self.dval[:b], self.g256[:R]
+        ops.fill_coef(dval, coef, idx, scale)
+        ops.gemm(dh3[:b], dval, P["model.9.weight"], False, False, epi=EPI_MUL, E=self.pm3[:b])
+        ops.mul(dh3[b:], dfeat, self.pm3[b:R])
+        dh2 = self.g512[:R]
+        ops.gemm(dh2, dh3, P["model.7.weight"], False, False, epi=EPI_MUL, E=self.pm2[:R])
+        da1 = self.g1024a[:R]
+        ops.gemm(da1, dh2, P["model.4.weight"], False, False)
+        dh0 = self.g1024b[:R]
+        ops.bn_bwd_seg(dh0, da1, self.h0[:R], None, self.pm1[:R], 2, self.stats[0], self.stats[1], P["model.1.weight"],
+                       None, None, False, 0.2)
+        dsum = self.dsum[:b]
+        ops.axpby(dsum, 1.0, dh0[:b], 1.0, dh0[b:])
+        ops.gemm(dx_out, dsum, P["model.0.weight"][:, :Gd], False, False, accumulate=True)
+
+    def gp_backward(self, b, seg, lambda_gp, red, slot):
+        """Segment `seg` holds the forward on the interpolates: first-order chain to the input gradient, the
+        penalty (row terms reduced into `slot`), and the second-order chain accumulating
+        d(lambda*penalty)/d(params)  (GAN_functions.py:194-204, :336-339)."""
+        ops, P, G, Gd = self.ops, self.net.P, self.net.G, self.Gd
+        sl = slice(seg * b, (seg + 1) * b)
+        mean, invstd = self.stats[0][seg], self.stats[1][seg]
+        h0, pm1, pm2, pm3, x, emb = self.h0[sl], self.pm1[sl], self.pm2[sl], self.pm3[sl], self.x[sl], self.emb[sl]
+        W1, W2, W3, w4 = P["model.0.weight"], P["model.4.weight"], P["model.7.weight"], P["model.9.weight"]
+        u3, u2, u1, u0 = self.g256[sl], self.g512[sl], self.g1024a[sl], self.g1024b[sl]
+        ops.gemm(u3, self.ones[:b], w4, False, False, epi=EPI_MUL, E=pm3)
+        ops.gemm(u2, u3, W3, False, False, epi=EPI_MUL, E=pm2)
+        ops.gemm(u1, u2, W2, False, False, epi=EPI_MUL, E=pm1)
+        ops.bn_bwd(u0, u1, h0, None, None, mean, invstd, P["model.1.weight"], None, None, False, 1.0, self.ubar,
+                   self.mbar)
+        ux = self.ux[:b]
+        ops.gemm(ux, u0, W1[:, :Gd], False, False)
+        ops.gp_penalty(ux, self.rowpen[:b], ux, lambda_gp)          # ux now holds V
+        ops.reduce_sum(red, slot, self.rowpen[:b])
+        gW1 = G["model.0.weight"]
+        ops.gemm(gW1[:, :Gd], u0, ux, True, False, accumulate=True)
+        w = self.h1024a[:b]
+        ops.gemm(w, ux, W1[:, :Gd], False, True)
+        vu1, vh0 = self.h1024b[:b], self.h1024a[:b]
+        ops.bn_bwd_bwd(vu1, vh0, G["model.1.weight"], True, w, u1, h0, mean, invstd, P["model.1.weight"], self.ubar,
+                       self.mbar)
+        t1 = vu1
+        ops.mul(t1, vu1, pm1)
+        ops.gemm(G["model.4.weight"], u2, t1, True, False, accumulate=True)
+        t2 = self.h512[:b]
+        ops.gemm(t2, t1, W2, False, True, epi=EPI_MUL, E=pm2)
+        ops.gemm(G["model.7.weight"], u3, t2, True, False, accumulate=True)
+        vu3 = self.h256[:b]
+        ops.gemm(vu3, t2, W3, False, True, epi=EPI_MUL, E=pm3)
+        ops.colsum(G["model.9.weight"], vu3, 1.0, True)
+        ops.gemm(gW1[:, :Gd], vh0, x, True, False, accumulate=True)
+        ops.gemm(gW1[:, Gd:], vh0, emb, True, False, accumulate=True)
+        if self.have_labels:
+            ops.gemm(self.demb[:b], vh0, W1[:, Gd:], False, False)
+            ops.embed_scatter(G["embeddings.0.weight"], self.demb[:b], self.lab[sl], True)
+
+
 # --------------------------------------------------------------------------- #
 class StepEngine:
     """State of a training run on one device + the two halves of an iteration."""
@@ -518,13 +690,11 @@ class StepEngine:
         N = self.nets
         self.gen_a = {"g_m2h": GenPass(self, N["g_m2h"], gm, gh, B), "g_h2m": GenPass(self, N["g_h2m"], gh, gm, B)}
         self.gen_b = {"g_m2h": GenPass(self, N["g_m2h"], gm, gh, B), "g_h2m": GenPass(self, N["g_h2m"], gh, gm, B)}
-        self.disc = {
-            "d_m": [DiscPass(self, N["d_m"], gm, B) for _ in range(3)],
-            "d_h": [DiscPass(self, N["d_h"], gh, B) for _ in range(3)],
-        }
+        # critic step: real | generated | interpolated; generator step: generated (adv, fm) | real
+        self.dstack = {"d_m": CriticStack(self, N["d_m"], gm, B, 3, 3), "d_h": CriticStack(self, N["d_h"], gh, B, 3, 3)}
+        self.gstack = {"d_m": CriticStack(self, N["d_m"], gm, B, 3, 2), "d_h": CriticStack(self, N["d_h"], gh, B, 3, 2)}
         Z = ops.zeros
         self.red = (Z(N_SLOTS, MAX_PARTS), Z(N_SLOTS, dtype=torch.int32))
-        self.xhat = {"d_m": Z(B, gm), "d_h": Z(B, gh)}
         self.d_fake = {"human": Z(B, gh), "mouse": Z(B, gm)}
         self.d_recov = {"mouse": Z(B, gm), "human": Z(B, gh)}
         self.fm_mean = {k: Z(256) for k in ("h_real", "h_fake", "m_real", "m_fake")}
@@ -572,6 +742,25 @@ class StepEngine:
         with torch.cuda.stream(self.side):   #  order as in a sequential run)
             second()
         main.wait_stream(self.side)
+
+    @staticmethod
+    def _critic_noise(noise, b, nseg, draw_order=None, alpha_before=None, first=None):
+        """Dropout keep masks of `nseg` stacked critic calls (+ the penalty's alpha).  A source that draws in HBM
+        makes one draw per layer for all segments; a replaying source is asked call by call, in the reference's
+        order `draw_order` of segments (two masks per call; alpha just before the call on the interpolates,
+        GAN_functions.py:196-199).  `first`: masks of segment 0 drawn earlier (the generator step's adversarial
+        call, :347)."""
+        alpha = None
+        if getattr(noise, "stacked_draws", False):
+            if alpha_before is not None:
+                alpha = noise.rand((b, 1))
+            return noise.keep((nseg * b, 1024), 0.3), noise.keep((nseg * b, 512), 0.3), alpha
+        pairs = {} if first is None else {0: first}
+        for sg in (range(nseg) if draw_order is None else draw_order):
+            if sg == alpha_before:
+                alpha = noise.rand((b, 1))
+            pairs[sg] = (noise.keep((b, 1024), 0.3), noise.keep((b, 512), 0.3))
+        return (torch.cat([pairs[i][0] for i in range(nseg)]), torch.cat([pairs[i][1] for i in range(nseg)]), alpha)
 
     # ---- optimizer ---------------------------------------------------------------
     def set_lr(self, lr):
@@ -682,18 +871,17 @@ class StepEngine:
         fake_human, fake_mouse = out["g_m2h"], out["g_h2m"]
 
         def critic(name, real, real_lab, fake, fake_lab, s0):
-            dp = self.disc[name][0]
-            val, _ = dp.forward(real, real_lab, noise)
-            ops.reduce_sum(self.red, s0, val)
-            dp.backward(self.one, 0, -1.0 / b, param_grads=True)
-            val, _ = dp.forward(fake, fake_lab, noise)
-            ops.reduce_sum(self.red, s0 + 1, val)
-            dp.backward(self.one, 0, 1.0 / b, param_grads=True)
-            alpha = noise.rand((b, 1))
-            xhat = self.xhat[name][:b]
-            ops.gp_interp(xhat, real, fake, alpha)
-            dp.forward(xhat, fake_lab, noise)
-            dp.gp_backward(cfg["lambda_gp"], self.red, s0 + 2)
+            ds = self.dstack[name]
+            ds.load(0, b, real, real_lab)
+            ds.load(1, b, fake, fake_lab)
+            ds.load(2, b, None, fake_lab)
+            m1, m2, alpha = self._critic_noise(noise, b, 3, alpha_before=2)
+            ops.gp_interp(ds.x_seg(2, b), real, fake, alpha)
+            val, _ = ds.forward(b, m1, m2, (0, 1, 2))
+            ops.reduce_sum(self.red, s0, val[:b])
+            ops.reduce_sum(self.red, s0 + 1, val[b:2 * b])
+            ds.backward_params(b, (-1.0 / b, 1.0 / b))
+            ds.gp_backward(b, 2, cfg["lambda_gp"], self.red, s0 + 2)
         self._two(lambda: critic("d_m", mouse, mouse_cat, fake_mouse, human_cat, S_DM_REAL),
                   lambda: critic("d_h", human, human_cat, fake_human, mouse_cat, S_DH_REAL))
 
@@ -726,8 +914,6 @@ class StepEngine:
         self.arena_g.g.zero_()
         A, Bp = self.gen_a["g_m2h"], self.gen_a["g_h2m"]
         Rm, Rh = self.gen_b["g_h2m"], self.gen_b["g_m2h"]
-        dh_adv, dh_fm, dh_tmp = self.disc["d_h"]
-        dm_adv, dm_fm, dm_tmp = self.disc["d_m"]
         red, o = self.red, {}
         # Forward, in the reference's call order (:344-372).  Each pair below is independent and may run on two
         # streams; the human-side member comes first, as in the reference, so a sequential run draws its noise in
@@ -738,10 +924,10 @@ class StepEngine:
         self._two(lambda: fwd("fh", A, mouse, mouse_cat), lambda: fwd("fm", Bp, human, human_cat))
         fake_human, fake_mouse = o["fh"], o["fm"]
 
-        def adv(dp, x, lab, slot):
-            val, _ = dp.forward(x, lab, noise)                              # :347
-            ops.reduce_sum(red, slot, val)
-        self._two(lambda: adv(dh_adv, fake_human, human_cat, S_ADV_H), lambda: adv(dm_adv, fake_mouse, mouse_cat, S_ADV_M))
+        adv_masks = {}
+        if not getattr(noise, "stacked_draws", False):      # the adversarial calls' masks, at the reference's place
+            for name in ("d_h", "d_m"):                                     # in the draw order (:347)
+                adv_masks[name] = (noise.keep((b, 1024), 0.3), noise.keep((b, 512), 0.3))
 
         def cyc(key, p, x, lab, target, slot):
             o[key] = p.forward(x, lab, noise)                               # :349-357
@@ -750,18 +936,24 @@ class StepEngine:
                   lambda: cyc("rh", Rh, fake_mouse, mouse_cat, human, S_CYC_H))
         recov_mouse, recov_human = o["rm"], o["rh"]
 
-        def ct_fm(fake, cents, src_lab, s_ct, d_tmp, d_fm, real, lab, m_real, m_fake, s_fm, gen_first, s_kl):
+        def critics(name, fake, real, lab, cents, src_lab, s_adv, s_ct, m_real, m_fake, s_fm, gen_first, s_kl):
+            # segments: adversarial call on the generated batch (:347) | feature call on it (:368,:371) | feature
+            # call on the real batch (:367,:370); the reference makes them in the order 0, 2, 1
+            gs = self.gstack[name]
+            gs.load(0, b, fake, lab)
+            gs.load(1, b, real, lab)
+            m1, m2, _ = self._critic_noise(noise, b, 3, draw_order=(2, 1), first=adv_masks.get(name))
+            val, feat = gs.forward(b, m1, m2, (0, 2, 1))
+            ops.reduce_sum(red, s_adv, val[:b])
             ops.reduce_centroid_sq(red, s_ct, fake, cents, src_lab)         # :363-364
-            _, f = d_tmp.forward(real, lab, noise)                          # :366-372
-            ops.colsum(self.fm_mean[m_real], f, 1.0 / b)
-            _, f = d_fm.forward(fake, lab, noise)
-            ops.colsum(self.fm_mean[m_fake], f, 1.0 / b)
+            ops.colsum(self.fm_mean[m_real], feat[2 * b:], 1.0 / b)         # :366-372
+            ops.colsum(self.fm_mean[m_fake], feat[b:2 * b], 1.0 / b)
             ops.reduce_sqdiff(red, s_fm, self.fm_mean[m_real], self.fm_mean[m_fake])
             ops.reduce_kl(red, s_kl, gen_first.ml[:b])                      # :375-376
-        self._two(lambda: ct_fm(fake_human, self.human_centroids, mouse_cat, S_CT_H, dh_tmp, dh_fm, human, human_cat,
-                                "h_real", "h_fake", S_FM_H, A, S_KL_H),
-                  lambda: ct_fm(fake_mouse, self.mouse_centroids, human_cat, S_CT_M, dm_tmp, dm_fm, mouse, mouse_cat,
-                                "m_real", "m_fake", S_FM_M, Bp, S_KL_M))
+        self._two(lambda: critics("d_h", fake_human, human, human_cat, self.human_centroids, mouse_cat, S_ADV_H, S_CT_H,
+                                  "h_real", "h_fake", S_FM_H, A, S_KL_H),
+                  lambda: critics("d_m", fake_mouse, mouse, mouse_cat, self.mouse_centroids, human_cat, S_ADV_M, S_CT_M,
+                                  "m_real", "m_fake", S_FM_M, Bp, S_KL_M))
         if self.sync.enabled:
             ops.sum_parts(self.g_tot, red, self.g_slots, self.g_ones)
         self._g_state = (mouse, human, mouse_cat, human_cat, o)
@@ -778,8 +970,6 @@ class StepEngine:
         gm, gh = self.g_mouse, self.g_human
         A, Bp = self.gen_a["g_m2h"], self.gen_a["g_h2m"]
         Rm, Rh = self.gen_b["g_h2m"], self.gen_b["g_m2h"]
-        dh_adv, dh_fm, _ = self.disc["d_h"]
-        dm_adv, dm_fm, _ = self.disc["d_m"]
         L = cfg["latent_dim"]
         if self.sync.enabled:
             red[0][S_ADV_H:S_ADV_H + 10, 0] = self.g_tot.to(red[0].dtype)
@@ -802,17 +992,16 @@ class StepEngine:
         # the cycle pass); mouse side likewise; then each first-pass generator.  The two sides touch disjoint buffers.
         dfh, dfm = self.d_fake["human"][:b], self.d_fake["mouse"][:b]
 
-        def side(dfake, fake, cents, src_lab, gdim, d_adv, d_fm, m_fake, m_real, dfe, drec, recov, target, tdim, R):
+        def side(dfake, fake, cents, src_lab, gdim, gs, m_fake, m_real, dfe, drec, recov, target, tdim, R):
             ops.centroid_bwd(dfake, fake, cents, src_lab, coef, 2, 2.0 / (b * gdim))
-            d_adv.backward(coef, 0, -1.0 / b, param_grads=False, dx_out=dfake)
             ops.fm_bwd(dfe, self.fm_mean[m_fake], self.fm_mean[m_real], coef, 3, 1.0 / (256 * b))
-            d_fm.backward(None, dfeat=dfe, param_grads=False, dx_out=dfake)
+            gs.backward_input(b, coef, 0, -1.0 / b, dfe, dfake)
             ops.l1_bwd(drec, recov, target, coef, 1, 1.0 / (b * tdim))
             R.backward(drec, need_dx=True, dx_out=dfake, dx_accumulate=True)
-        self._two(lambda: side(dfh, fake_human, self.human_centroids, mouse_cat, gh, dh_adv, dh_fm, "h_fake", "h_real",
-                               self.d_feat[:b], self.d_recov["mouse"][:b], recov_mouse, mouse, gm, Rm),
-                  lambda: side(dfm, fake_mouse, self.mouse_centroids, human_cat, gm, dm_adv, dm_fm, "m_fake", "m_real",
-                               self.d_feat2[:b], self.d_recov["human"][:b], recov_human, human, gh, Rh))
+        self._two(lambda: side(dfh, fake_human, self.human_centroids, mouse_cat, gh, self.gstack["d_h"], "h_fake",
+                               "h_real", self.d_feat[:b], self.d_recov["mouse"][:b], recov_mouse, mouse, gm, Rm),
+                  lambda: side(dfm, fake_mouse, self.mouse_centroids, human_cat, gm, self.gstack["d_m"], "m_fake",
+                               "m_real", self.d_feat2[:b], self.d_recov["human"][:b], recov_human, human, gh, Rh))
         self._two(lambda: A.backward(dfh, kl=(coef, 4, 1.0)), lambda: Bp.backward(dfm, kl=(coef, 4, 1.0)))
 
     def _g_grad_comm(self):

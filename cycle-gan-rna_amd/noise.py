@@ -58,6 +58,8 @@ class DeviceNoise:
     """Draws straight into HBM.  Buffers are reused per (kind, shape, call index
     within a step) so that a captured step replays with fresh numbers."""
 
+    stacked_draws = True     # one draw serves several stacked calls of a module (no reference draw order to follow)
+
     def __init__(self, device, seed=0, default_generator=False):
         """default_generator=True draws from torch's default CUDA generator (seeded
         here), which HIP-graph capture supports; otherwise a private generator is used."""

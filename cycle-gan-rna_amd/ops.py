@@ -74,9 +74,9 @@ class HipOps:
         with torch.cuda.stream(stream):
             self._ws()
 
-    def _bnws(self, M, N):
+    def _bnws(self, M, N, nseg=1):
         ws = self._ws()
-        need = self.lib.cg_bn_workspace_bytes(M, N)
+        need = self.lib.cg_bn_workspace_bytes(M, N) * nseg
         if need > ws[1].numel() * 8:
             ws[1] = torch.empty(need // 8 + 1, dtype=torch.float64, device=self.device)
         return C.c_void_p(ws[1].data_ptr()), ws[1].numel() * 8
@@ -89,8 +89,9 @@ class HipOps:
         """Returns (launches, total milliseconds, executed FLOP, operand + result bytes) since begin_gemm_timing()."""
         torch.cuda.synchronize(self.device)
         ev, self._gemm_events = self._gemm_events, None
-        return (len(ev), sum(a.elapsed_time(b) for a, b, _, _ in ev), sum(f for _, _, f, _ in ev),
-                sum(by for _, _, _, by in ev))
+        self.last_gemm_detail = [(shape, a.elapsed_time(b), f) for a, b, f, _, shape in ev]
+        return (len(ev), sum(t for _, t, _ in self.last_gemm_detail), sum(f for _, _, f, _, _ in ev),
+                sum(by for _, _, _, by, _ in ev))
 
     # -- plumbing -------------------------------------------------------------
     def _stream(self):
@@ -131,7 +132,8 @@ class HipOps:
         if self._gemm_events is not None:
             e1.record(torch.cuda.current_stream(self.device))
             self._gemm_events.append((e0, e1, 2.0 * M * N * K,
-                                      4.0 * (M * K + K * N + M * N * (2 if accumulate else 1))))
+                                      4.0 * (M * K + K * N + M * N * (2 if accumulate else 1)),
+                                      (M, N, K, int(transA), int(transB), int(accumulate), dtype)))
         _lib.check(st, "cg_gemm")
 
     def gemm_untimed(self, *args, **kw):
@@ -151,6 +153,34 @@ class HipOps:
                                 _ptr(invstd), _ptr(rmean), _ptr(rvar), momentum, float(slope), _ptr(mask), _ld(mask),
                                 _ptr(pm), _ld(pm), None, 0, *self._bnws(M, N), self._stream())
         _lib.check(st, "cg_bn_fwd")
+
+    @staticmethod
+    def _order_code(order, nseg):
+        order = tuple(range(nseg)) if order is None else tuple(order)
+        assert sorted(order) == list(range(nseg)), order
+        return sum(s << (4 * k) for k, s in enumerate(order))
+
+    def bn_fwd_seg(self, Y, X, nseg, order, gamma, beta, mean, invstd, rmean, rvar, slope, mask=None, pm=None,
+                   eps=1e-5, momentum=0.1):
+        """bn_fwd on nseg equal row segments, each with its own batch statistics; mean/invstd: (nseg, N)."""
+        M, N = X.shape
+        assert M % nseg == 0 and Y.shape == X.shape and gamma.numel() == N
+        assert mean.numel() >= nseg * N and invstd.numel() >= nseg * N and mean.is_contiguous() and invstd.is_contiguous()
+        st = self.lib.cg_bn_fwd_seg(_ptr(Y), _ld(Y), _ptr(X), _ld(X), M // nseg, nseg, self._order_code(order, nseg), N,
+                                    _ptr(gamma), _ptr(beta), eps, _ptr(mean), _ptr(invstd), _ptr(rmean), _ptr(rvar),
+                                    momentum, float(slope), _ptr(mask), _ld(mask), _ptr(pm), _ld(pm), None, 0,
+                                    *self._bnws(M // nseg, N, nseg), self._stream())
+        _lib.check(st, "cg_bn_fwd_seg")
+
+    def bn_bwd_seg(self, dX, dY, X, Y, PM, nseg, mean, invstd, gamma, dgamma, dbeta, accumulate, slope):
+        M, N = X.shape
+        assert M % nseg == 0 and dX.shape == X.shape and dY.shape == X.shape
+        assert mean.numel() >= nseg * N and invstd.numel() >= nseg * N
+        st = self.lib.cg_bn_bwd_seg(_ptr(dX), _ld(dX), _ptr(dY), _ld(dY), _ptr(X), _ld(X), _ptr(Y), _ld(Y), _ptr(PM),
+                                    _ld(PM), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(dgamma), _ptr(dbeta),
+                                    int(accumulate), None, None, float(slope), M // nseg, nseg, N,
+                                    *self._bnws(M // nseg, N, nseg), self._stream())
+        _lib.check(st, "cg_bn_bwd_seg")
 
     def bn_eval(self, Y, X, gamma, beta, rmean, rvar, slope, eps=1e-5):
         M, N = X.shape

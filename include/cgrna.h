@@ -89,6 +89,25 @@ int cg_bn_fwd(float* Y, int ldy, const float* X, int ldx, int M, int N,
               void* ybf16, int ldybf16, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * cg_bn_fwd on `nseg` (1..8) equal row segments of X at once: segment s is rows
+ * [s*seg_rows, (s+1)*seg_rows) and is normalised with its own batch statistics,
+ * exactly as a separate call of the module on that batch would
+ * (the critic is called on the real, the generated and the interpolated batch
+ * in a row, GAN_functions.py:326-336, and three times per species in the
+ * generator step, :347,:366-371).  mean_out/invstd_out hold nseg*N values,
+ * segment-major.  The running statistics receive one update per segment, in
+ * the order given by `order`: 4 bits per position, position k holds the
+ * segment updated k-th (the order in which the reference makes the calls).
+ * workspace: nseg * cg_bn_workspace_bytes(seg_rows, N) bytes.
+ */
+int cg_bn_fwd_seg(float* Y, int ldy, const float* X, int ldx, int seg_rows, int nseg,
+                  unsigned order, int N, const float* gamma, const float* beta, float eps,
+                  float* mean_out, float* invstd_out, float* running_mean, float* running_var,
+                  float momentum, float slope, const float* mask, int ldmask,
+                  float* pm_out, int ldpm, void* ybf16, int ldybf16,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * Eval-mode BatchNorm1d + activation (g_m2h.eval() translation pass,
  * GAN_functions.py:461-468): Y = act(gamma*(x-rm)/sqrt(rv+eps)+beta).
  */
@@ -111,6 +130,20 @@ int cg_bn_bwd(float* dX, int lddx, const float* dY, int lddy, const float* X, in
               float* dgamma, float* dbeta, int accumulate,
               float* gbar_out, float* gxbar_out, float slope, int M, int N,
               void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * cg_bn_bwd on the `nseg` row segments of a cg_bn_fwd_seg call (mean/invstd
+ * segment-major): dX per segment from that segment's statistics; dgamma/dbeta
+ * (+)= the sum over all segments, added in segment order (what accumulating
+ * .backward() calls of the separate batches give, GAN_functions.py:328-339).
+ * gbar_out/gxbar_out: nseg*N values.
+ */
+int cg_bn_bwd_seg(float* dX, int lddx, const float* dY, int lddy, const float* X, int ldx,
+                  const float* Y, int ldy, const float* PM, int ldpm,
+                  const float* mean, const float* invstd, const float* gamma,
+                  float* dgamma, float* dbeta, int accumulate,
+                  float* gbar_out, float* gxbar_out, float slope, int seg_rows, int nseg, int N,
+                  void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * BatchNorm backward-of-backward for the gradient penalty

@@ -80,6 +80,26 @@ class CpuOps:
         if pm is not None:
             pm.copy_(p)
 
+    def bn_fwd_seg(self, Y, X, nseg, order, gamma, beta, mean, invstd, rmean, rvar, slope, mask=None, pm=None,
+                   eps=1e-5, momentum=0.1):
+        """One bn_fwd per row segment; running statistics updated in `order`."""
+        M, N = X.shape
+        b = M // nseg
+        mean, invstd = mean.view(-1)[:nseg * N].view(nseg, N), invstd.view(-1)[:nseg * N].view(nseg, N)
+        for s in (range(nseg) if order is None else order):
+            sl = slice(s * b, (s + 1) * b)
+            self.bn_fwd(Y[sl], X[sl], gamma, beta, mean[s], invstd[s], rmean, rvar, slope,
+                        None if mask is None else mask[sl], None if pm is None else pm[sl], eps, momentum)
+
+    def bn_bwd_seg(self, dX, dY, X, Y, PM, nseg, mean, invstd, gamma, dgamma, dbeta, accumulate, slope):
+        M, N = X.shape
+        b = M // nseg
+        mean, invstd = mean.view(-1)[:nseg * N].view(nseg, N), invstd.view(-1)[:nseg * N].view(nseg, N)
+        for s in range(nseg):
+            sl = slice(s * b, (s + 1) * b)
+            self.bn_bwd(dX[sl], dY[sl], X[sl], None if Y is None else Y[sl], None if PM is None else PM[sl],
+                        mean[s], invstd[s], gamma, dgamma, dbeta, accumulate or s > 0, slope)
+
     def bn_eval(self, Y, X, gamma, beta, rmean, rvar, slope, eps=1e-5):
         h = (X - rmean) * (1.0 / torch.sqrt(rvar + eps)) * gamma + beta
         Y.copy_(torch.where(h > 0, h, h * slope))

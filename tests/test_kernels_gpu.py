@@ -183,6 +183,44 @@ def test_bn_fwd_bwd(ops, M, N, slope, use_mask):
         close(g, e, 1e-4, f"bn_bwd {w}")
 
 
+@pytest.mark.parametrize("b,nseg,order,N", [(512, 3, (0, 1, 2), 1024), (512, 3, (0, 2, 1), 1024), (37, 2, (1, 0), 100),
+                                            (500, 3, (0, 2, 1), 1024)])
+def test_bn_segments(ops, b, nseg, order, N):
+    """Several batches normalised in one launch equal separate calls, running statistics updated in the given order."""
+    M = b * nseg
+    X = rnd(M, N, seed=1) * 2 + 0.7 + torch.arange(M)[:, None] / M            # segments have different statistics
+    gamma, beta = rnd(N, seed=2) + 1.5, rnd(N, seed=3)
+    mask = (torch.rand(M, N, generator=torch.Generator().manual_seed(4)) < 0.7).float() / 0.7
+    rm, rv = rnd(N, seed=5), rnd(N, seed=6).abs() + 0.5
+    c64 = CpuOps(torch.float64)
+    d = lambda t: None if t is None else t.double()  # noqa: E731
+    eY, epm = torch.empty(M, N, dtype=torch.float64), torch.empty(M, N, dtype=torch.float64)
+    emean, einv = torch.empty(nseg, N, dtype=torch.float64), torch.empty(nseg, N, dtype=torch.float64)
+    erm, erv = rm.double().clone(), rv.double().clone()
+    c64.bn_fwd_seg(eY, d(X), nseg, order, d(gamma), d(beta), emean, einv, erm, erv, 0.2, d(mask), epm)
+    gY, gpm = torch.empty(M, N).cuda(), torch.empty(M, N).cuda()
+    gmean, ginv, grm, grv = torch.empty(nseg, N).cuda(), torch.empty(nseg, N).cuda(), dev(rm.clone()), dev(rv.clone())
+    Xd = dev(X)
+    ops.bn_fwd_seg(gY, Xd, nseg, order, dev(gamma), dev(beta), gmean, ginv, grm, grv, 0.2, dev(mask), gpm)
+    for g, e, w in [(gY, eY, "Y"), (gmean, emean, "mean"), (ginv, einv, "invstd"), (grm, erm, "rmean"), (grv, erv, "rvar")]:
+        close(g, e, 3e-5, f"bn_fwd_seg {w}")
+    # one launch == separate launches, bit for bit (same kernels, same geometry per segment)
+    sY, spm = torch.empty(M, N).cuda(), torch.empty(M, N).cuda()
+    smean, sinv, srm, srv = torch.empty(nseg, N).cuda(), torch.empty(nseg, N).cuda(), dev(rm.clone()), dev(rv.clone())
+    for sg in order:
+        sl = slice(sg * b, (sg + 1) * b)
+        ops.bn_fwd(sY[sl], Xd[sl], dev(gamma), dev(beta), smean[sg], sinv[sg], srm, srv, 0.2, dev(mask)[sl], spm[sl])
+    assert torch.equal(sY, gY) and torch.equal(srm, grm) and torch.equal(srv, grv) and torch.equal(smean, gmean)
+    dY = rnd(M, N, seed=7)
+    edX = torch.empty(M, N, dtype=torch.float64)
+    edg, edb = torch.ones(N, dtype=torch.float64), torch.ones(N, dtype=torch.float64)
+    c64.bn_bwd_seg(edX, d(dY), d(X), None, epm, nseg, emean, einv, d(gamma), edg, edb, True, 0.2)
+    gdX, gdg, gdb = torch.empty(M, N).cuda(), torch.ones(N).cuda(), torch.ones(N).cuda()
+    ops.bn_bwd_seg(gdX, dev(dY), Xd, None, gpm, nseg, gmean, ginv, dev(gamma), gdg, gdb, True, 0.2)
+    for g, e, w in [(gdX, edX, "dX"), (gdg, edg, "dgamma"), (gdb, edb, "dbeta")]:
+        close(g, e, 1e-4, f"bn_bwd_seg {w}")
+
+
 def test_bn_bwd_matches_autograd():
     """The CPU restatement of the BatchNorm backward itself against torch autograd (float64)."""
     M, N = 24, 10
