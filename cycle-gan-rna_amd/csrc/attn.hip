@@ -339,12 +339,23 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(float* __restrict__ dX, f
   }
 }
 
-__global__ void attn_param_reduce_kernel(float* dparams, const float* wpart, int n_blocks, int accumulate) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= NPARAM) return;
+// 32 parameters per block; 8 lanes per parameter walk the per-block partials, then a fixed-order combine.
+__global__ void __launch_bounds__(256) attn_param_reduce_kernel(float* dparams, const float* wpart, int n_blocks,
+                                                                int accumulate) {
+  __shared__ float lds[8][32];
+  const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
+  const int t = blockIdx.x * 32 + c;
   float s = 0.f;
-  for (int b = 0; b < n_blocks; ++b) s += wpart[(size_t)b * NPARAM + t];
-  dparams[t] = (accumulate ? dparams[t] : 0.f) + s;
+  if (t < NPARAM)
+    for (int b = r; b < n_blocks; b += 8) s += wpart[(size_t)b * NPARAM + t];
+  lds[r][c] = s;
+  __syncthreads();
+  if (r == 0 && t < NPARAM) {
+    float a = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a += lds[i][c];
+    dparams[t] = (accumulate ? dparams[t] : 0.f) + a;
+  }
 }
 
 }  // namespace
@@ -378,7 +389,7 @@ extern "C" int cg_attn_ln_bwd(float* dX, float* dparams, float* wpart, const flo
   const int iters = (n_cells + nb * 4 - 1) / (nb * 4);
   hipLaunchKernelGGL(attn_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dX, wpart, dY, X, keep, params,
                      n_cells, iters);
-  hipLaunchKernelGGL(attn_param_reduce_kernel, dim3((NPARAM + 255) / 256), dim3(256), 0, (hipStream_t)stream, dparams,
+  hipLaunchKernelGGL(attn_param_reduce_kernel, dim3((NPARAM + 31) / 32), dim3(256), 0, (hipStream_t)stream, dparams,
                      wpart, nb, accumulate);
   return cg_launch_status();
 }

@@ -56,16 +56,16 @@ __global__ void embed_gather_kernel(float* out, int ldo, const float* table, int
   out[(size_t)m * ldo + e] = table[t * E + e];
 }
 
-// One block per table row (cell type): 8 row lanes x 32 column lanes walk the batch, then the row lanes are
+// One block per table row (cell type): 32 row lanes x 32 column lanes walk the batch, then the row lanes are
 // combined through LDS in a fixed order (deterministic; embedding widths up to 128).
-__global__ void __launch_bounds__(256) embed_scatter_kernel(float* dtable, int E, const float* dout, int lddo,
+__global__ void __launch_bounds__(1024) embed_scatter_kernel(float* dtable, int E, const float* dout, int lddo,
                                                             const int64_t* labels, int lstride, int M, int n_types,
                                                             int accumulate) {
-  __shared__ float lds[8][128];
+  __shared__ float lds[32][128];
   const int t = blockIdx.x;
   const int el = threadIdx.x & 31, rl = threadIdx.x >> 5;
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int m = rl; m < M; m += 8) {
+  for (int m = rl; m < M; m += 32) {
     if (labels[(size_t)m * lstride] != t) continue;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -76,10 +76,10 @@ __global__ void __launch_bounds__(256) embed_scatter_kernel(float* dtable, int E
 #pragma unroll
   for (int u = 0; u < 4; ++u) lds[rl][el + 32 * u] = acc[u];
   __syncthreads();
-  for (int e = threadIdx.x; e < E; e += 256) {
+  for (int e = threadIdx.x; e < E; e += 1024) {
     float s = 0.f;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) s += lds[r][e];
+    for (int r = 0; r < 32; ++r) s += lds[r][e];
     dtable[t * E + e] = (accumulate ? dtable[t * E + e] : 0.f) + s;
   }
 }
@@ -218,19 +218,19 @@ __global__ void __launch_bounds__(256) reduce_kl_kernel(float* parts, int* npart
 }
 
 // Column statistics with the 32-column strip layout of bn.hip.
-__global__ void __launch_bounds__(256) colsum_kernel(float* out, const float* X, int ldx, int M, int N, float scale,
-                                                     int accumulate) {
-  __shared__ double lds[8 * 32];
+__global__ void __launch_bounds__(1024) colsum_kernel(float* out, const float* X, int ldx, int M, int N, float scale,
+                                                      int accumulate) {
+  __shared__ double lds[32 * 32];
   const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
   const int col = blockIdx.x * 32 + c;
   double s = 0.0;
   if (col < N)
-    for (int m = r0; m < M; m += 8) s += X[(size_t)m * ldx + col];
+    for (int m = r0; m < M; m += 32) s += X[(size_t)m * ldx + col];
   lds[r0 * 32 + c] = s;
   __syncthreads();
   if (r0 == 0 && col < N) {
     double a = 0.0;
-    for (int r = 0; r < 8; ++r) a += lds[r * 32 + c];
+    for (int r = 0; r < 32; ++r) a += lds[r * 32 + c];
     out[col] = (accumulate ? out[col] : 0.f) + (float)(a * (double)scale);
   }
 }
@@ -305,18 +305,22 @@ __global__ void fm_bwd_kernel(float* dF, int ldd, const float* mf, const float* 
   }
 }
 
-// ---- loss bookkeeping (float64, one thread: a few hundred adds) ------------ //
+// ---- loss bookkeeping (float64) ------------ //
+// Sum of a slot's per-block partials by one wave: lane l adds entries l, l+64, ... then the lanes are combined by
+// a fixed shuffle tree, so the result does not depend on timing.  Every lane returns the total.
 __device__ double sum_slot(const float* parts, const int* nparts, int slot) {
   double s = 0.0;
-  const int n = nparts[slot];
+  int n = nparts[slot];
+  if (n > CG_MAX_PARTS) n = CG_MAX_PARTS;
   const float* p = parts + (size_t)slot * CG_MAX_PARTS;
-  for (int i = 0; i < n && i < CG_MAX_PARTS; ++i) s += (double)p[i];
+  for (int i = threadIdx.x & 63; i < n; i += 64) s += (double)p[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
   return s;
 }
 
-__global__ void gloss_finalize_kernel(double* ema, double* losses, float* coef, const float* parts, const int* nparts,
-                                      cg_gloss_desc d) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ void __launch_bounds__(64) gloss_finalize_kernel(double* ema, double* losses, float* coef, const float* parts,
+                                                            const int* nparts, cg_gloss_desc d) {
   double L[5];
   for (int k = 0; k < 5; ++k) {
     // each term is rounded to float32 like the tensor the reference calls .item() on
@@ -324,6 +328,7 @@ __global__ void gloss_finalize_kernel(double* ema, double* losses, float* coef, 
     for (int j = 0; j < d.n_terms[k]; ++j) acc = acc + (float)(d.weight[k][j] * sum_slot(parts, nparts, d.slot[k][j]));
     L[k] = (double)acc;
   }
+  if (threadIdx.x != 0) return;
   const double a = d.ema_alpha;
   double sc[5];
   for (int k = 0; k < 5; ++k) ema[k] = a * L[k] + (1.0 - a) * ema[k];
@@ -343,10 +348,11 @@ __global__ void gloss_finalize_kernel(double* ema, double* losses, float* coef, 
   losses[5] = g;
 }
 
-__global__ void sum_parts_kernel(double* totals, const float* parts, const int* nparts, const int* slots,
-                                 const double* scales, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) totals[i] = scales[i] * sum_slot(parts, nparts, slots[i]);
+__global__ void __launch_bounds__(64) sum_parts_kernel(double* totals, const float* parts, const int* nparts,
+                                                       const int* slots, const double* scales, int n) {
+  const int i = blockIdx.x;      // one wave per slot
+  const double s = sum_slot(parts, nparts, slots[i]);
+  if (threadIdx.x == 0) totals[i] = scales[i] * s;
 }
 
 }  // namespace
@@ -400,7 +406,7 @@ extern "C" int cg_embed_scatter(float* dtable, int E, const float* dout, int ldd
                                 int M, int n_types, int accumulate, void* stream) {
   if (!dtable || !dout || !labels || E <= 0 || M < 0 || lddo < E || lstride < 1 || n_types <= 0) return CG_ERR_BAD_ARG;
   if (E > 128) return CG_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(embed_scatter_kernel, dim3(n_types), dim3(256), 0, ST, dtable, E, dout, lddo, labels, lstride, M,
+  hipLaunchKernelGGL(embed_scatter_kernel, dim3(n_types), dim3(1024), 0, ST, dtable, E, dout, lddo, labels, lstride, M,
                      n_types, accumulate);
   return cg_launch_status();
 }
@@ -489,7 +495,7 @@ extern "C" int cg_reduce_kl(float* parts, int* nparts, const float* ml, int ldml
 extern "C" int cg_colsum(float* out, const float* X, int ldx, int M, int N, float scale, int accumulate,
                          void* stream) {
   if (!out || !X || M <= 0 || N <= 0 || ldx < N) return CG_ERR_BAD_ARG;
-  hipLaunchKernelGGL(colsum_kernel, dim3((N + 31) / 32), dim3(256), 0, ST, out, X, ldx, M, N, scale, accumulate);
+  hipLaunchKernelGGL(colsum_kernel, dim3((N + 31) / 32), dim3(1024), 0, ST, out, X, ldx, M, N, scale, accumulate);
   return cg_launch_status();
 }
 
@@ -551,7 +557,7 @@ extern "C" int cg_gloss_finalize(double* ema_state, double* losses_out, float* c
 extern "C" int cg_sum_parts(double* totals, const float* parts, const int* nparts, const int* slots,
                             const double* scales, int n, void* stream) {
   if (!totals || !parts || !nparts || !slots || !scales || n <= 0) return CG_ERR_BAD_ARG;
-  hipLaunchKernelGGL(sum_parts_kernel, dim3((n + 63) / 64), dim3(64), 0, ST, totals, parts, nparts, slots, scales, n);
+  hipLaunchKernelGGL(sum_parts_kernel, dim3(n), dim3(64), 0, ST, totals, parts, nparts, slots, scales, n);
   return cg_launch_status();
 }
 
