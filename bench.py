@@ -89,6 +89,7 @@ def main():
                     help="f32: exact float32 MFMA everywhere; bf16: large dense-layer products on the bf16 MFMA")
     ap.add_argument("--sequential", action="store_true", help="one stream instead of two")
     ap.add_argument("--gemm-shapes", action="store_true", help="print the per-shape GEMM time table to stderr")
+    ap.add_argument("--only", choices=["d", "g"], help="diagnostic: time only critic steps or only generator steps")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying HIP graphs")
     a = ap.parse_args()
 
@@ -126,8 +127,9 @@ def main():
     def step(i):
         s = (i % 16) * B
         noise.begin_step()
-        eng.d_step(xm[s:s + B], xh[s:s + B], lm[s:s + B], lh[s:s + B], noise)
-        if i % NB_CRITIC == 0:
+        if a.only != "g":
+            eng.d_step(xm[s:s + B], xh[s:s + B], lm[s:s + B], lh[s:s + B], noise)
+        if (i % NB_CRITIC == 0 and a.only != "d") or a.only == "g":
             eng.g_step(xm[s:s + B], xh[s:s + B], lm[s:s + B], lh[s:s + B], noise)
 
     def fence():

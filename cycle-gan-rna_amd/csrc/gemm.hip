@@ -12,6 +12,8 @@
 // 32x32x2 MFMA consumes two k values per step (lane half h = lane>>5 supplies
 // one of them); both operands use k = 8c + 4h + s for step s of group c, so the
 // sum covers every k exactly once whatever the storage.
+#include <cstdio>
+#include <cstdlib>
 #include "common.h"
 
 namespace {
@@ -455,32 +457,37 @@ extern "C" int cg_gemm(float* C, int ldc, const void* A, int lda, const void* B,
   GemmArgs g{(const float*)A, (const float*)B, C, bias, E, aux, M, N, K, lda, ldb, ldc, lde, ldaux,
              epi, accumulate, slope, 0, 1 << 30, (float*)workspace};
   const bool vec = (((uintptr_t)A | (uintptr_t)B) % 16 == 0) && (lda % 4 == 0) && (ldb % 4 == 0);
-  // Tile and split-K choice by a small cost model: a K slab of a tile costs max(MFMA cycles, staged bytes at
-  // ~10 B/clk/CU); the launch takes ceil(blocks / 256 CUs) rounds of (slabs per split) such slabs, plus the slab
-  // round trip of the partial sums when K is split.  Large tiles stage fewer bytes per FLOP, splits fill the chip.
-  // (bf16: a 64-deep slab is bound by the float32 bytes staged, ~20 B/clk/CU from L2.)
+  // Tile and split-K choice by a cost model fitted to a sweep of the step's shapes on MI355X (microseconds).
+  // A workgroup alone on a CU needs L per K slab (latency-bound); n workgroups sharing a CU overlap and finish a
+  // slab every S (throughput-bound), so the busiest CU takes slabs * max(L, n*S).  Small tiles have the worse S but
+  // fill 256 CUs evenly, which decides every shape of this workload except the very large ones.  Splitting K adds
+  // a fixed cost and the round trip of the partial sums.
   const int nk = half ? (K + BKH - 1) / BKH : (K + BK - 1) / BK;
   const size_t per = (size_t)M * N * sizeof(float);
-  struct Cand { int bm, bn; double slab; } cands[3] = {{128, 128, half ? 3277.0 : 4096.0},
-                                                       {128, 64, 2458.0}, {64, 64, 1638.0}};
+  struct Cand { int bm, bn; double L, S, P; };
+  static const Cand cand_f32[3] = {{128, 128, 2.45, 2.21, 6.0}, {128, 64, 1.48, 1.232, 4.0}, {64, 64, 1.0, 0.64, 2.5}};
+  static const Cand cand_bf16[3] = {{128, 128, 1.2, 0.65, 6.0}, {128, 64, 0.8, 0.45, 4.0}, {64, 64, 0.9, 0.25, 2.5}};
+  const Cand* cands = half ? cand_bf16 : cand_f32;
+  static const int split_choices[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
   int best = 2, best_splits = 1;
   double best_cost = 1e300;
   for (int c = 0; c < 3; ++c) {
     const long tiles = (long)((M + cands[c].bm - 1) / cands[c].bm) * ((N + cands[c].bn - 1) / cands[c].bn);
-    int smax = 1;
-    if (workspace && nk >= (half ? 8 : 16)) {
-      smax = nk / (half ? 4 : 8);
-      if (smax > 32) smax = 32;
-      if ((size_t)smax * per > workspace_bytes) smax = (int)(workspace_bytes / per);
-      if (smax < 1) smax = 1;
-    }
-    for (int sp = 1; sp <= smax; sp = sp < 4 ? sp + 1 : sp * 2) {
+    for (int sp : split_choices) {
+      if (sp > 1 && (!workspace || (size_t)sp * per > workspace_bytes || nk / sp < 4)) break;
       const long blocks = tiles * sp;
-      const long rounds = (blocks + 255) / 256;
+      const long n = (blocks + 255) / 256;
       const int slabs = (nk + sp - 1) / sp;
-      double cost = (double)rounds * (slabs * cands[c].slab + 3000.0);
-      if (sp > 1) cost += 2.0 * sp * (double)per / (256.0 * 10.0) + 4000.0;
+      double cost = slabs * (n * cands[c].S > cands[c].L ? n * cands[c].S : cands[c].L) + cands[c].P * (accumulate ? 1.5 : 1.0);
+      if (sp > 1) cost += 6.0 + (sp + 1) * (double)per / 4.0e6;
       if (cost < best_cost) { best_cost = cost; best = c; best_splits = sp; }
+    }
+  }
+  if (const char* f = getenv("CGRNA_GEMM_FORCE")) {   // tuning aid: "tile,splits" with tile 0=128x128 1=128x64 2=64x64
+    int t = 0, sp = 1;
+    if (sscanf(f, "%d,%d", &t, &sp) == 2 && t >= 0 && t < 3 && sp >= 1 && (sp == 1 || (workspace && (size_t)sp * per <= workspace_bytes))) {
+      best = t;
+      best_splits = sp;
     }
   }
   if (half) {
