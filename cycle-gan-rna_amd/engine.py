@@ -48,7 +48,7 @@ class Arena:
     Adam state), with named views.  Every tensor starts on a 16-byte boundary;
     the padding stays zero (zero gradient keeps Adam's update at zero)."""
 
-    def __init__(self, ops, named_shapes):
+    def __init__(self, ops, named_shapes, second_grad=False):
         self.ops = ops
         self.offsets = OrderedDict()
         off = 0
@@ -59,6 +59,9 @@ class Arena:
         self.n = off
         self.p = ops.zeros(off)
         self.g = ops.zeros(off)
+        # second gradient buffer: lets two backward chains of one network run side by side without both
+        # accumulating into the same tensors; added to `g` before the optimizer step
+        self.g2 = ops.zeros(off) if second_grad else None
         self.m = ops.zeros(off)
         self.v = ops.zeros(off)
         self.vmax = ops.zeros(off)
@@ -102,6 +105,7 @@ class Net:
         self.name = name
         self.P = OrderedDict((k, arena.view(arena.p, (name, k))) for k in keys)
         self.G = OrderedDict((k, arena.view(arena.g, (name, k))) for k in keys)
+        self.G2 = OrderedDict((k, arena.view(arena.g2, (name, k))) for k in keys) if arena.g2 is not None else None
         self.B = OrderedDict()
         self.nbt = OrderedDict()
         for k, v in buffers.items():
@@ -517,6 +521,7 @@ class CriticStack:
         self.h256, self.h512, self.h1024a, self.h1024b = Z(B, 256), Z(B, 512), Z(B, 1024), Z(B, 1024)
         self.dsum = Z(B, 1024)
         self.demb = Z(nx * B, self.E)
+        self.demb2 = Z(B, self.E)
         self.ux = Z(B, in_dim)
         self.rowpen = Z(B)
         self.ubar, self.mbar = Z(1024), Z(1024)
@@ -619,8 +624,10 @@ class CriticStack:
     def gp_backward(self, b, seg, lambda_gp, red, slot):
         """Segment `seg` holds the forward on the interpolates: first-order chain to the input gradient, the
         penalty (row terms reduced into `slot`), and the second-order chain accumulating
-        d(lambda*penalty)/d(params)  (GAN_functions.py:194-204, :336-339)."""
-        ops, P, G, Gd = self.ops, self.net.P, self.net.G, self.Gd
+        d(lambda*penalty)/d(params)  (GAN_functions.py:194-204, :336-339).  The parameter gradients go to the
+        network's second gradient buffer, each tensor overwritten on first touch (the tensors this chain never
+        touches - biases - stay zero there), so the chain can run beside backward_params."""
+        ops, P, G, Gd = self.ops, self.net.P, self.net.G2, self.Gd
         sl = slice(seg * b, (seg + 1) * b)
         mean, invstd = self.stats[0][seg], self.stats[1][seg]
         h0, pm1, pm2, pm3, x, emb = self.h0[sl], self.pm1[sl], self.pm2[sl], self.pm3[sl], self.x[sl], self.emb[sl]
@@ -636,26 +643,26 @@ class CriticStack:
         ops.gp_penalty(ux, self.rowpen[:b], ux, lambda_gp)          # ux now holds V
         ops.reduce_sum(red, slot, self.rowpen[:b])
         gW1 = G["model.0.weight"]
-        ops.gemm(gW1[:, :Gd], u0, ux, True, False, accumulate=True)
+        ops.gemm(gW1[:, :Gd], u0, ux, True, False)
         w = self.h1024a[:b]
         ops.gemm(w, ux, W1[:, :Gd], False, True)
         vu1, vh0 = self.h1024b[:b], self.h1024a[:b]
-        ops.bn_bwd_bwd(vu1, vh0, G["model.1.weight"], True, w, u1, h0, mean, invstd, P["model.1.weight"], self.ubar,
+        ops.bn_bwd_bwd(vu1, vh0, G["model.1.weight"], False, w, u1, h0, mean, invstd, P["model.1.weight"], self.ubar,
                        self.mbar)
         t1 = vu1
         ops.mul(t1, vu1, pm1)
-        ops.gemm(G["model.4.weight"], u2, t1, True, False, accumulate=True)
+        ops.gemm(G["model.4.weight"], u2, t1, True, False)
         t2 = self.h512[:b]
         ops.gemm(t2, t1, W2, False, True, epi=EPI_MUL, E=pm2)
-        ops.gemm(G["model.7.weight"], u3, t2, True, False, accumulate=True)
+        ops.gemm(G["model.7.weight"], u3, t2, True, False)
         vu3 = self.h256[:b]
         ops.gemm(vu3, t2, W3, False, True, epi=EPI_MUL, E=pm3)
-        ops.colsum(G["model.9.weight"], vu3, 1.0, True)
+        ops.colsum(G["model.9.weight"], vu3, 1.0, False)
         ops.gemm(gW1[:, :Gd], vh0, x, True, False, accumulate=True)
-        ops.gemm(gW1[:, Gd:], vh0, emb, True, False, accumulate=True)
+        ops.gemm(gW1[:, Gd:], vh0, emb, True, False)
         if self.have_labels:
-            ops.gemm(self.demb[:b], vh0, W1[:, Gd:], False, False)
-            ops.embed_scatter(G["embeddings.0.weight"], self.demb[:b], self.lab[sl], True)
+            ops.gemm(self.demb2[:b], vh0, W1[:, Gd:], False, False)
+            ops.embed_scatter(G["embeddings.0.weight"], self.demb2[:b], self.lab[sl], False)
 
 
 # --------------------------------------------------------------------------- #
@@ -674,7 +681,8 @@ class StepEngine:
         split = {n: split_state(sd) for n, sd in nets.items()}
         order = {n: _arena_order(list(split[n][0].keys())) for n in nets}
         self.arena_g = Arena(ops, [((n, k), tuple(split[n][0][k].shape)) for n in ("g_m2h", "g_h2m") for k in order[n]])
-        self.arena_d = Arena(ops, [((n, k), tuple(split[n][0][k].shape)) for n in ("d_m", "d_h") for k in order[n]])
+        self.arena_d = Arena(ops, [((n, k), tuple(split[n][0][k].shape)) for n in ("d_m", "d_h") for k in order[n]],
+                             second_grad=True)
         self.nets = {}
         for n in ("g_m2h", "g_h2m", "d_m", "d_h"):
             arena = self.arena_g if n.startswith("g_") else self.arena_d
@@ -697,6 +705,7 @@ class StepEngine:
         self.red = (Z(N_SLOTS, MAX_PARTS), Z(N_SLOTS, dtype=torch.int32))
         self.d_fake = {"human": Z(B, gh), "mouse": Z(B, gm)}
         self.d_recov = {"mouse": Z(B, gm), "human": Z(B, gh)}
+        self.d_cyc = {"human": Z(B, gh), "mouse": Z(B, gm)}       # d(cycle loss)/d(generated batch)
         self.fm_mean = {k: Z(256) for k in ("h_real", "h_fake", "m_real", "m_fake")}
         self.d_feat = Z(B, 256)
         self.one = ops.to_device(torch.ones(1))
@@ -725,23 +734,33 @@ class StepEngine:
         streams.  They are independent between a few join points, and most kernels of one half
         leave much of the chip idle at batch 512, so the halves overlap.  Only for noise that is
         drawn on the device: the order of draws then differs from the reference's call order."""
-        self.side = torch.cuda.Stream(device=self.ops.device)
-        self.ops.prepare_stream(self.side)
+        self.sides = [torch.cuda.Stream(device=self.ops.device) for _ in range(3)]
+        for st in self.sides:
+            self.ops.prepare_stream(st)
         self.ops.prepare_stream(torch.cuda.current_stream(self.ops.device))
         self.concurrent = True
 
-    def _two(self, first, second):
-        """Run first() on the current stream and second() on the side stream, then join."""
+    def _many(self, *branches):
+        """Run independent branches side by side: the first on the current stream, the others on side streams
+        that start from what the current stream has queued so far; then join.  The host calls them in the order
+        given, so noise is drawn in the same order as in a sequential run."""
         if not self.concurrent:
-            first()
-            second()
+            for fn in branches:
+                fn()
             return
         main = torch.cuda.current_stream(self.ops.device)
-        self.side.wait_stream(main)          # the side stream starts from what the main stream has queued so far
-        first()                              # (host call order stays first, second: noise is drawn in the same
-        with torch.cuda.stream(self.side):   #  order as in a sequential run)
-            second()
-        main.wait_stream(self.side)
+        used = self.sides[:len(branches) - 1]
+        for st in used:
+            st.wait_stream(main)
+        branches[0]()
+        for st, fn in zip(used, branches[1:]):
+            with torch.cuda.stream(st):
+                fn()
+        for st in used:
+            main.wait_stream(st)
+
+    def _two(self, first, second):
+        self._many(first, second)
 
     @staticmethod
     def _critic_noise(noise, b, nseg, draw_order=None, alpha_before=None, first=None):
@@ -870,7 +889,7 @@ class StepEngine:
         self._two(lambda: gen("g_m2h", mouse, mouse_cat), lambda: gen("g_h2m", human, human_cat))
         fake_human, fake_mouse = out["g_m2h"], out["g_h2m"]
 
-        def critic(name, real, real_lab, fake, fake_lab, s0):
+        def critic_fwd(name, real, real_lab, fake, fake_lab, s0):
             ds = self.dstack[name]
             ds.load(0, b, real, real_lab)
             ds.load(1, b, fake, fake_lab)
@@ -880,10 +899,15 @@ class StepEngine:
             val, _ = ds.forward(b, m1, m2, (0, 1, 2))
             ops.reduce_sum(self.red, s0, val[:b])
             ops.reduce_sum(self.red, s0 + 1, val[b:2 * b])
-            ds.backward_params(b, (-1.0 / b, 1.0 / b))
-            ds.gp_backward(b, 2, cfg["lambda_gp"], self.red, s0 + 2)
-        self._two(lambda: critic("d_m", mouse, mouse_cat, fake_mouse, human_cat, S_DM_REAL),
-                  lambda: critic("d_h", human, human_cat, fake_human, mouse_cat, S_DH_REAL))
+        self._many(lambda: critic_fwd("d_m", mouse, mouse_cat, fake_mouse, human_cat, S_DM_REAL),
+                   lambda: critic_fwd("d_h", human, human_cat, fake_human, mouse_cat, S_DH_REAL))
+        # per critic two independent backward chains: Wasserstein terms (real, generated) into the gradient
+        # arena, penalty (double backward on the interpolates) into the second gradient buffer
+        self._many(lambda: self.dstack["d_m"].backward_params(b, (-1.0 / b, 1.0 / b)),
+                   lambda: self.dstack["d_m"].gp_backward(b, 2, cfg["lambda_gp"], self.red, S_DM_REAL + 2),
+                   lambda: self.dstack["d_h"].backward_params(b, (-1.0 / b, 1.0 / b)),
+                   lambda: self.dstack["d_h"].gp_backward(b, 2, cfg["lambda_gp"], self.red, S_DH_REAL + 2))
+        self.arena_d.g.add_(self.arena_d.g2)
 
     def _d_comm(self):
         self.sync.launch(self.arena_d.g)
@@ -932,9 +956,6 @@ class StepEngine:
         def cyc(key, p, x, lab, target, slot):
             o[key] = p.forward(x, lab, noise)                               # :349-357
             ops.reduce_l1(red, slot, o[key], target)
-        self._two(lambda: cyc("rm", Rm, fake_human, human_cat, mouse, S_CYC_M),
-                  lambda: cyc("rh", Rh, fake_mouse, mouse_cat, human, S_CYC_H))
-        recov_mouse, recov_human = o["rm"], o["rh"]
 
         def critics(name, fake, real, lab, cents, src_lab, s_adv, s_ct, m_real, m_fake, s_fm, gen_first, s_kl):
             # segments: adversarial call on the generated batch (:347) | feature call on it (:368,:371) | feature
@@ -950,10 +971,13 @@ class StepEngine:
             ops.colsum(self.fm_mean[m_fake], feat[b:2 * b], 1.0 / b)
             ops.reduce_sqdiff(red, s_fm, self.fm_mean[m_real], self.fm_mean[m_fake])
             ops.reduce_kl(red, s_kl, gen_first.ml[:b])                      # :375-376
-        self._two(lambda: critics("d_h", fake_human, human, human_cat, self.human_centroids, mouse_cat, S_ADV_H, S_CT_H,
-                                  "h_real", "h_fake", S_FM_H, A, S_KL_H),
-                  lambda: critics("d_m", fake_mouse, mouse, mouse_cat, self.mouse_centroids, human_cat, S_ADV_M, S_CT_M,
-                                  "m_real", "m_fake", S_FM_M, Bp, S_KL_M))
+        # the cycle passes and the critic calls only need the generated batches: four independent branches
+        self._many(lambda: cyc("rm", Rm, fake_human, human_cat, mouse, S_CYC_M),
+                   lambda: cyc("rh", Rh, fake_mouse, mouse_cat, human, S_CYC_H),
+                   lambda: critics("d_h", fake_human, human, human_cat, self.human_centroids, mouse_cat, S_ADV_H, S_CT_H,
+                                   "h_real", "h_fake", S_FM_H, A, S_KL_H),
+                   lambda: critics("d_m", fake_mouse, mouse, mouse_cat, self.mouse_centroids, human_cat, S_ADV_M, S_CT_M,
+                                   "m_real", "m_fake", S_FM_M, Bp, S_KL_M))
         if self.sync.enabled:
             ops.sum_parts(self.g_tot, red, self.g_slots, self.g_ones)
         self._g_state = (mouse, human, mouse_cat, human_cat, o)
@@ -992,16 +1016,23 @@ class StepEngine:
         # the cycle pass); mouse side likewise; then each first-pass generator.  The two sides touch disjoint buffers.
         dfh, dfm = self.d_fake["human"][:b], self.d_fake["mouse"][:b]
 
-        def side(dfake, fake, cents, src_lab, gdim, gs, m_fake, m_real, dfe, drec, recov, target, tdim, R):
+        def crit(dfake, fake, cents, src_lab, gdim, gs, m_fake, m_real, dfe):
             ops.centroid_bwd(dfake, fake, cents, src_lab, coef, 2, 2.0 / (b * gdim))
             ops.fm_bwd(dfe, self.fm_mean[m_fake], self.fm_mean[m_real], coef, 3, 1.0 / (256 * b))
             gs.backward_input(b, coef, 0, -1.0 / b, dfe, dfake)
+
+        def cycb(drec, recov, target, tdim, R, dx):
             ops.l1_bwd(drec, recov, target, coef, 1, 1.0 / (b * tdim))
-            R.backward(drec, need_dx=True, dx_out=dfake, dx_accumulate=True)
-        self._two(lambda: side(dfh, fake_human, self.human_centroids, mouse_cat, gh, self.gstack["d_h"], "h_fake",
-                               "h_real", self.d_feat[:b], self.d_recov["mouse"][:b], recov_mouse, mouse, gm, Rm),
-                  lambda: side(dfm, fake_mouse, self.mouse_centroids, human_cat, gm, self.gstack["d_m"], "m_fake",
-                               "m_real", self.d_feat2[:b], self.d_recov["human"][:b], recov_human, human, gh, Rh))
+            R.backward(drec, need_dx=True, dx_out=dx)
+        dch, dcm = self.d_cyc["human"][:b], self.d_cyc["mouse"][:b]
+        self._many(lambda: crit(dfh, fake_human, self.human_centroids, mouse_cat, gh, self.gstack["d_h"], "h_fake",
+                                "h_real", self.d_feat[:b]),
+                   lambda: cycb(self.d_recov["mouse"][:b], recov_mouse, mouse, gm, Rm, dch),
+                   lambda: crit(dfm, fake_mouse, self.mouse_centroids, human_cat, gm, self.gstack["d_m"], "m_fake",
+                                "m_real", self.d_feat2[:b]),
+                   lambda: cycb(self.d_recov["human"][:b], recov_human, human, gh, Rh, dcm))
+        ops.axpby(dfh, 1.0, dfh, 1.0, dch)
+        ops.axpby(dfm, 1.0, dfm, 1.0, dcm)
         self._two(lambda: A.backward(dfh, kl=(coef, 4, 1.0)), lambda: Bp.backward(dfm, kl=(coef, 4, 1.0)))
 
     def _g_grad_comm(self):
