@@ -87,6 +87,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32: exact float32 MFMA everywhere; bf16: large dense-layer products on the bf16 MFMA")
+    ap.add_argument("--no-bf16-line", action="store_true", help="skip the secondary bf16-MFMA measurement of an f32 run")
     ap.add_argument("--sequential", action="store_true", help="one stream instead of two")
     ap.add_argument("--gemm-shapes", action="store_true", help="print the per-shape GEMM time table to stderr")
     ap.add_argument("--only", choices=["d", "g"], help="diagnostic: time only critic steps or only generator steps")
@@ -217,6 +218,41 @@ def main():
                     executed_tflops=exec_flop / (gemm_ms * 1e-3) / 1e12)
     if world > 1:
         dist.barrier()
+    other = None
+    if a.dtype == "f32" and not a.no_bf16_line and not a.only:
+        # the named configuration compares float32 with bf16 MFMA: time the same step with the large dense-layer
+        # products on the bf16 matrix cores (float32 operands rounded on the fly, float32 accumulate)
+        ops16 = HipOps(dev, precision="bf16")
+        eng16 = StepEngine(nets, cfg, cm, ch, ops16, B)
+        if not a.sequential:
+            eng16.enable_concurrency()
+        if not a.eager:
+            eng16.enable_graphs()
+
+        def step16(i):
+            s = (i % 16) * B
+            noise.begin_step()
+            eng16.d_step(xm[s:s + B], xh[s:s + B], lm[s:s + B], lh[s:s + B], noise)
+            if i % NB_CRITIC == 0:
+                eng16.g_step(xm[s:s + B], xh[s:s + B], lm[s:s + B], lh[s:s + B], noise)
+        for i in range(2 if eng16.use_graphs else 0):
+            step16(0)
+        for i in range(a.warmup):
+            step16(i)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            step16(i)
+        fence()
+        dt16 = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt16], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt16 = float(t.item())
+        l16 = {**eng16.d_losses(), **eng16.g_losses()}
+        assert all(v == v and abs(v) < 1e30 for v in l16.values() if isinstance(v, float)), l16
+        other = dict(dtype="bf16", value=B * world * a.steps / dt16, unit="cells/s", ms_per_step=dt16 / a.steps * 1e3,
+                     note="same step, dense-layer products with M,N>=128, K>=256 on v_mfma_f32_16x16x32_bf16")
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline()
@@ -229,7 +265,7 @@ def main():
                                    f"hidden 2048/1024/512, latent 256, {N_TYPES} cell types, log-normalised synthetic "
                                    f"expression, {'bf16 MFMA for the large layers' if a.dtype == 'bf16' else 'float32 MFMA'}", "global_batch": B * world,
                        "parallelism": f"dp{world}"},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "cpu_baseline": cpu, "bf16_mfma": other,
         }
         print(json.dumps(line))
     if world > 1:

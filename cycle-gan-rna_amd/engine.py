@@ -221,6 +221,9 @@ class GenPass:
         self.eps = noise.randn((b, L))
         ops.reparam_fwd(self.z[0][:b], ml, self.eps)
         t = b * SEQ_LEN
+        all_keep = None
+        if train and getattr(noise, "stacked_draws", False):     # one draw for the attention dropout of every block
+            all_keep = noise.keep((self.nb, b * self.heads, SEQ_LEN, SEQ_LEN), 0.1)
         for bi in range(self.nb):
             pre = f"residual_attention_blocks.{bi}"
             zin = self.z[bi][:b].view(t, 16)
@@ -241,7 +244,10 @@ class GenPass:
             else:
                 ops.bn_eval(u, t2, g2, b2, rm2, rv2, 1.0)
             ops.axpby(y, 1.0, zin, 1.0, u)
-            self.keep[bi] = noise.keep((b * self.heads, SEQ_LEN, SEQ_LEN), 0.1) if train else None
+            if all_keep is not None:
+                self.keep[bi] = all_keep[bi]
+            else:
+                self.keep[bi] = noise.keep((b * self.heads, SEQ_LEN, SEQ_LEN), 0.1) if train else None
             ops.attn_fwd(self.z[bi + 1][:b].view(t, 16), y, self.keep[bi], self._attn("p", bi), self.heads)
         dec_in = self.dec_in[:b]
         ops.axpby(dec_in[:, :L], 1.0, self.z[self.nb][:b])
