@@ -172,21 +172,7 @@ def main():
                 ops.gemm_untimed(filler_c, filler_a, filler_a, False, True)
             step(i)
         torch.cuda.synchronize()
-        n_launch, gemm_ms_raw, exec_flop, gemm_bytes = ops.end_gemm_timing()
-        # An event pair with nothing between its two records does not read zero: the records are commands of their
-        # own on the stream.  That cost is measured the same way (behind filler work) and taken off every launch, so
-        # the figure is kernel time, the quantity rocprofv3 reports.
-        for _ in range(24):
-            ops.gemm_untimed(filler_c, filler_a, filler_a, False, True)
-        pairs = []
-        for _ in range(200):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            e1.record()
-            pairs.append((e0, e1))
-        torch.cuda.synchronize()
-        empty_ms = sorted(p[0].elapsed_time(p[1]) for p in pairs)[len(pairs) // 2]
-        gemm_ms = sum(max(ms - empty_ms, 0.0) for _, ms, _ in ops.last_gemm_detail)
+        n_launch, gemm_ms, exec_flop, gemm_bytes = ops.end_gemm_timing()
         if a.gemm_shapes:
             agg = {}
             for shape, ms, fl in ops.last_gemm_detail:
@@ -214,7 +200,6 @@ def main():
                     operand_bytes_per_launch=gemm_bytes / n_launch,
                     kernel=kname, launches_per_iteration=n_launch / NB_CRITIC,
                     avg_launch_us=gemm_ms * 1e3 / n_launch, gemm_ms_per_iteration=gemm_ms / NB_CRITIC,
-                    event_pair_overhead_us=empty_ms * 1e3, raw_event_ms_per_iteration=gemm_ms_raw / NB_CRITIC,
                     executed_tflops=exec_flop / (gemm_ms * 1e-3) / 1e12)
     if world > 1:
         dist.barrier()

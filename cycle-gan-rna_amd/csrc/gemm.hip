@@ -113,6 +113,20 @@ __device__ __forceinline__ int xcd_tile() {
   return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
 }
 
+// Tile index -> (tile row, tile column).  Within an XCD's contiguous run the tiles are walked column-first inside
+// bands of GROUP_M tile rows, so the workgroups that are resident together (32 CUs x up to 4) cover a compact
+// patch of the output: the A row panels and B column panels they share stay within that XCD's 4 MB L2 instead of
+// sweeping a whole row of tiles (all of B) at a time.
+constexpr int GROUP_M = 8;
+__device__ __forceinline__ void tile_coords(int tile, int tiles_m, int tiles_n, int& tm, int& tn) {
+  const int band = tile / (GROUP_M * tiles_n);
+  const int first = band * GROUP_M;
+  const int rows = min(GROUP_M, tiles_m - first);
+  const int r = tile - band * GROUP_M * tiles_n;
+  tm = first + r % rows;
+  tn = r / rows;
+}
+
 // ------------------------------------------------------------------------------------------------
 // bf16 path: float32 operands in memory, rounded to bf16 while they are staged into LDS, multiplied
 // with v_mfma_f32_16x16x32_bf16 (float32 accumulate).  Both operand kinds end up in LDS as
@@ -190,7 +204,9 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgs g) {
   __shared__ __align__(16) u16 smem[2 * (A_ELEMS + B_ELEMS)];
 
   const int tile = xcd_tile();
-  const int bm = (tile / g.tiles_n) * BM, bn = (tile % g.tiles_n) * BN;
+  int tile_m, tile_n;
+  tile_coords(tile, (g.M + BM - 1) / BM, g.tiles_n, tile_m, tile_n);
+  const int bm = tile_m * BM, bn = tile_n * BN;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
   const int lr = lane & 15, lg = lane >> 4;
@@ -273,7 +289,9 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
   __shared__ __align__(16) float smem[2 * (A_ELEMS + B_ELEMS)];
 
   const int tile = xcd_tile();
-  const int bm = (tile / g.tiles_n) * BM, bn = (tile % g.tiles_n) * BN;
+  int tile_m, tile_n;
+  tile_coords(tile, (g.M + BM - 1) / BM, g.tiles_n, tile_m, tile_n);
+  const int bm = tile_m * BM, bn = tile_n * BN;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
   const int li = lane & 31, lh = lane >> 5;
