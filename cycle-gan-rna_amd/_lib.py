@@ -32,6 +32,14 @@ SIGNATURES = {
     "cg_bn_fwd": ([P, I, P, I, I, I, P, P, F, P, P, P, P, F, F, P, I, P, I, P, I, P, Z, P], I),
     "cg_bn_fwd_seg": ([P, I, P, I, I, I, C.c_uint, I, P, P, F, P, P, P, P, F, F, P, I, P, I, P, I, P, Z, P], I),
     "cg_bn_bwd_seg": ([P, I, P, I, P, I, P, I, P, I, P, P, P, P, P, I, P, P, F, I, I, I, P, Z, P], I),
+    "cg_tok_blocks": ([I], I),
+    "cg_tok_lin_fwd": ([P, P, P, P, P, I, P], I),
+    "cg_tok_bn_lin_fwd": ([P, P, P, P, P, P, P, F, P, P, P, P, F, P, P, I, P], I),
+    "cg_tok_bn_res_fwd": ([P, P, P, P, P, F, P, P, P, P, F, P, I, P], I),
+    "cg_tok_bn_bwd_stats": ([P, P, P, P, P, I, P], I),
+    "cg_tok_bwd_mid": ([P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, P], I),
+    "cg_tok_bwd_in": ([P, P, P, P, P, P, P, P, P, P, P, P, P, I, P], I),
+    "cg_tok_wgrad_reduce": ([P, P, P, P, I, P], I),
     "cg_bn_eval": ([P, I, P, I, I, I, P, P, P, P, F, F, P], I),
     "cg_bn_bwd": ([P, I, P, I, P, I, P, I, P, I, P, P, P, P, P, I, P, P, F, I, I, P, Z, P], I),
     "cg_bn_bwd_bwd": ([P, I, P, I, P, I, P, I, P, I, P, I, P, P, P, P, P, I, I, P, Z, P], I),

@@ -165,6 +165,9 @@ class GenPass:
         self.u = Z(T, 16)
         self.rb_stats = [((Z(16), Z(16)), (Z(16), Z(16))) for _ in range(self.nb)]
         self.keep = [None] * self.nb
+        nblk = max(ops.tok_blocks(T), 1)
+        self.tok_stat = [Z(nblk * 32, dtype=torch.float64) for _ in range(4)]     # per-workgroup column sums
+        self.tok_wpart = [Z(nblk * 256), Z(nblk * 256)]                           # per-workgroup 16x16 weight grads
         self.dec_in = Z(B, L + self.E)
         self.dec_h0 = [Z(B, h) for h in H]
         self.dec_a = [Z(B, h) for h in H]
@@ -229,21 +232,23 @@ class GenPass:
             zin = self.z[bi][:b].view(t, 16)
             t1, r, t2, y, u = self.t1[bi][:t], self.r[bi][:t], self.t2[bi][:t], self.y[bi][:t], self.u[:t]
             (s1, s2) = self.rb_stats[bi]
-            ops.gemm(t1, zin, P[pre + ".0.block.0.weight"], False, True, bias=P[pre + ".0.block.0.bias"])
             g1, b1, rm1, rv1 = self._bn(pre + ".0.block.1")
             g2, b2, rm2, rv2 = self._bn(pre + ".0.block.4")
-            if train:
-                ops.bn_fwd(r, t1, g1, b1, s1[0], s1[1], rm1, rv1, 0.0)
+            W1, c1 = P[pre + ".0.block.0.weight"], P[pre + ".0.block.0.bias"]
+            W2, c2 = P[pre + ".0.block.3.weight"], P[pre + ".0.block.3.bias"]
+            if train:       # three fused launches: Linear | BatchNorm+ReLU+Linear | BatchNorm+residual
+                sa, sb = self.tok_stat[0], self.tok_stat[1]
+                ops.tok_lin_fwd(t1, sa, zin, W1, c1)
+                ops.tok_bn_lin_fwd(r, t2, sb, t1, sa, g1, b1, s1[0], s1[1], rm1, rv1, W2, c2)
+                ops.tok_bn_res_fwd(y, t2, sb, g2, b2, s2[0], s2[1], rm2, rv2, zin)
                 self.net.nbt[pre + ".0.block.1.num_batches_tracked"] += 1
-            else:
-                ops.bn_eval(r, t1, g1, b1, rm1, rv1, 0.0)
-            ops.gemm(t2, r, P[pre + ".0.block.3.weight"], False, True, bias=P[pre + ".0.block.3.bias"])
-            if train:
-                ops.bn_fwd(u, t2, g2, b2, s2[0], s2[1], rm2, rv2, 1.0)
                 self.net.nbt[pre + ".0.block.4.num_batches_tracked"] += 1
             else:
+                ops.gemm(t1, zin, W1, False, True, bias=c1)
+                ops.bn_eval(r, t1, g1, b1, rm1, rv1, 0.0)
+                ops.gemm(t2, r, W2, False, True, bias=c2)
                 ops.bn_eval(u, t2, g2, b2, rm2, rv2, 1.0)
-            ops.axpby(y, 1.0, zin, 1.0, u)
+                ops.axpby(y, 1.0, zin, 1.0, u)
             if all_keep is not None:
                 self.keep[bi] = all_keep[bi]
             else:
@@ -315,17 +320,17 @@ class GenPass:
             dy = self.dz[1 - cur][:b].view(t, 16)
             ops.attn_bwd(dy, self._attn("g", bi), self.attn_ws, dz, self.y[bi][:t], self.keep[bi], self._attn("p", bi),
                          self.heads, True)
-            dt2, dr = self.d16[0][:t], self.d16[1][:t]
-            ops.bn_bwd(dt2, dy, self.t2[bi][:t], None, None, s2[0], s2[1], P[pre + ".0.block.4.weight"],
-                       G[pre + ".0.block.4.weight"], G[pre + ".0.block.4.bias"], True, 1.0)
-            ops.gemm(G[pre + ".0.block.3.weight"], dt2, self.r[bi][:t], True, False, accumulate=True)
-            ops.gemm(dr, dt2, P[pre + ".0.block.3.weight"], False, False)
-            dt1 = dt2
-            ops.bn_bwd(dt1, dr, self.t1[bi][:t], self.r[bi][:t], None, s1[0], s1[1], P[pre + ".0.block.1.weight"],
-                       G[pre + ".0.block.1.weight"], G[pre + ".0.block.1.bias"], True, 0.0)
+            s3, s4 = self.tok_stat[2], self.tok_stat[3]
+            wp2, wp1 = self.tok_wpart
+            g1buf = self.d16[0][:t]
             zin = self.z[bi][:b].view(t, 16)
-            ops.gemm(G[pre + ".0.block.0.weight"], dt1, zin, True, False, accumulate=True)
-            ops.gemm(dy, dt1, P[pre + ".0.block.0.weight"], False, False, accumulate=True)   # dzin = dy + dt1 L0
+            ops.tok_bn_bwd_stats(s3, dy, self.t2[bi][:t], s2[0], s2[1])
+            ops.tok_bwd_mid(g1buf, s4, wp2, G[pre + ".0.block.4.weight"], G[pre + ".0.block.4.bias"], dy,
+                            self.t2[bi][:t], self.r[bi][:t], self.t1[bi][:t], s3, s2[0], s2[1],
+                            P[pre + ".0.block.4.weight"], P[pre + ".0.block.3.weight"], s1[0], s1[1])
+            ops.tok_bwd_in(dy, wp1, G[pre + ".0.block.1.weight"], G[pre + ".0.block.1.bias"], g1buf, self.t1[bi][:t],
+                           zin, dy, s4, s1[0], s1[1], P[pre + ".0.block.1.weight"], P[pre + ".0.block.0.weight"])
+            ops.tok_wgrad_reduce(G[pre + ".0.block.3.weight"], G[pre + ".0.block.0.weight"], wp2, wp1, t)
             cur = 1 - cur
             dz = dy
         dz0 = self.dz[cur][:b]

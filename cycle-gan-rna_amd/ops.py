@@ -381,6 +381,66 @@ class HipOps:
                                       eps, None, self._stream())
         _lib.check(st, "cg_adam_amsgrad")
 
+    # -- latent ResidualBlock on tokens (fused) ------------------------------------------
+    def tok_blocks(self, n_tok):
+        return self.lib.cg_tok_blocks(n_tok)
+
+    def tok_lin_fwd(self, T1, stat_out, X, W, b):
+        n = X.shape[0]
+        assert X.shape == (n, 16) and T1.shape == (n, 16) and X.is_contiguous() and T1.is_contiguous()
+        assert stat_out.dtype == torch.float64 and stat_out.numel() >= self.tok_blocks(n) * 32
+        _lib.check(self.lib.cg_tok_lin_fwd(_ptr(T1), _ptr(stat_out), _ptr(X), _ptr(W), _ptr(b), n, self._stream()),
+                   "cg_tok_lin_fwd")
+
+    def tok_bn_lin_fwd(self, R, T2, stat_out, T1, stat_in, gamma, beta, mean, invstd, rmean, rvar, W2, b2, eps=1e-5,
+                       momentum=0.1):
+        n = T1.shape[0]
+        assert all(t.shape == (n, 16) and t.is_contiguous() for t in (R, T2, T1))
+        assert stat_out.numel() >= self.tok_blocks(n) * 32 and stat_in.numel() >= self.tok_blocks(n) * 32
+        _lib.check(self.lib.cg_tok_bn_lin_fwd(_ptr(R), _ptr(T2), _ptr(stat_out), _ptr(T1), _ptr(stat_in), _ptr(gamma),
+                                              _ptr(beta), eps, _ptr(mean), _ptr(invstd), _ptr(rmean), _ptr(rvar),
+                                              momentum, _ptr(W2), _ptr(b2), n, self._stream()), "cg_tok_bn_lin_fwd")
+
+    def tok_bn_res_fwd(self, Y, T2, stat_in, gamma, beta, mean, invstd, rmean, rvar, X, eps=1e-5, momentum=0.1):
+        n = T2.shape[0]
+        assert all(t.shape == (n, 16) and t.is_contiguous() for t in (Y, T2, X))
+        assert stat_in.numel() >= self.tok_blocks(n) * 32
+        _lib.check(self.lib.cg_tok_bn_res_fwd(_ptr(Y), _ptr(T2), _ptr(stat_in), _ptr(gamma), _ptr(beta), eps,
+                                              _ptr(mean), _ptr(invstd), _ptr(rmean), _ptr(rvar), momentum, _ptr(X), n,
+                                              self._stream()), "cg_tok_bn_res_fwd")
+
+    def tok_bn_bwd_stats(self, stat_out, dY, T2, mean, invstd):
+        n = dY.shape[0]
+        assert all(t.shape == (n, 16) and t.is_contiguous() for t in (dY, T2))
+        assert stat_out.numel() >= self.tok_blocks(n) * 32
+        _lib.check(self.lib.cg_tok_bn_bwd_stats(_ptr(stat_out), _ptr(dY), _ptr(T2), _ptr(mean), _ptr(invstd), n,
+                                                self._stream()), "cg_tok_bn_bwd_stats")
+
+    def tok_bwd_mid(self, G1, stat_out, wpart, dgamma2, dbeta2, dY, T2, R, T1, stat_in, mean2, invstd2, gamma2, W2,
+                    mean1, invstd1):
+        n = dY.shape[0]
+        assert all(t.shape == (n, 16) and t.is_contiguous() for t in (G1, dY, T2, R, T1))
+        nb = self.tok_blocks(n)
+        assert stat_out.numel() >= nb * 32 and stat_in.numel() >= nb * 32 and wpart.numel() >= nb * 256
+        _lib.check(self.lib.cg_tok_bwd_mid(_ptr(G1), _ptr(stat_out), _ptr(wpart), _ptr(dgamma2), _ptr(dbeta2), _ptr(dY),
+                                           _ptr(T2), _ptr(R), _ptr(T1), _ptr(stat_in), _ptr(mean2), _ptr(invstd2),
+                                           _ptr(gamma2), _ptr(W2), _ptr(mean1), _ptr(invstd1), n, self._stream()),
+                   "cg_tok_bwd_mid")
+
+    def tok_bwd_in(self, dX, wpart, dgamma1, dbeta1, G1, T1, X, dY, stat_in, mean1, invstd1, gamma1, W1):
+        n = dY.shape[0]
+        assert all(t.shape == (n, 16) and t.is_contiguous() for t in (dX, G1, T1, X, dY))
+        nb = self.tok_blocks(n)
+        assert stat_in.numel() >= nb * 32 and wpart.numel() >= nb * 256
+        _lib.check(self.lib.cg_tok_bwd_in(_ptr(dX), _ptr(wpart), _ptr(dgamma1), _ptr(dbeta1), _ptr(G1), _ptr(T1),
+                                          _ptr(X), _ptr(dY), _ptr(stat_in), _ptr(mean1), _ptr(invstd1), _ptr(gamma1),
+                                          _ptr(W1), n, self._stream()), "cg_tok_bwd_in")
+
+    def tok_wgrad_reduce(self, dW2, dW1, wpart2, wpart1, n_tok):
+        assert dW2.numel() == 256 and dW1.numel() == 256 and dW2.is_contiguous() and dW1.is_contiguous()
+        _lib.check(self.lib.cg_tok_wgrad_reduce(_ptr(dW2), _ptr(dW1), _ptr(wpart2), _ptr(wpart1), n_tok,
+                                                self._stream()), "cg_tok_wgrad_reduce")
+
     # -- attention ------------------------------------------------------------------
     def attn_fwd(self, Y, X, keep, params, heads):
         n_cells = X.numel() // 256

@@ -275,6 +275,53 @@ int cg_sum_parts(double* totals, const float* parts, const int* nparts, const in
                  int n, void* stream);
 
 /*
+ * ResidualBlock of the latent stage on the token view of the latent
+ * (GAN_functions.py:54-68: x + BN(Linear(ReLU(BN(Linear(x))))) with Linear(16,16),
+ * applied to the (batch*16, 16) token matrix at :129-132).  All matrices are dense
+ * (n_tok, 16) float32, 16-byte aligned; W is [out][in] like nn.Linear.weight.
+ * Column statistics travel between launches as per-workgroup float64 partial
+ * sums: `stat_*` buffers hold cg_tok_blocks(n_tok)*32 doubles, `wpart*` buffers
+ * cg_tok_blocks(n_tok)*256 floats.  Train mode only (batch statistics).
+ *   forward:
+ *     cg_tok_lin_fwd      T1 = X W1^T + b1;  stat_out <- sums of T1, T1^2
+ *     cg_tok_bn_lin_fwd   R = relu(bn1(T1)); T2 = R W2^T + b2; stat_out <- sums of T2, T2^2;
+ *                         mean_out/invstd_out (16) saved, running stats updated (momentum, unbiased var)
+ *     cg_tok_bn_res_fwd   Y = X + bn2(T2); mean/invstd saved, running stats updated
+ *   backward (autograd of the same lines), given dY = dL/dY:
+ *     cg_tok_bn_bwd_stats stat_out <- sums of dY, dY*xhat2
+ *     cg_tok_bwd_mid      dT2 = bn2'(dY); wpart <- partial dT2^T R; dgamma2/dbeta2 += ;
+ *                         G1 = (dT2 W2) * (R > 0); stat_out <- sums of G1, G1*xhat1
+ *     cg_tok_bwd_in       dT1 = bn1'(G1); wpart <- partial dT1^T X; dgamma1/dbeta1 += ;
+ *                         dX = dY + dT1 W1
+ *     cg_tok_wgrad_reduce dW2 += sum of wpart2, dW1 += sum of wpart1 (workgroup order)
+ * The Linear biases feed a BatchNorm, so their gradient is identically zero and is not produced.
+ */
+int cg_tok_blocks(int n_tok);
+int cg_tok_lin_fwd(float* T1, double* stat_out, const float* X, const float* W, const float* b,
+                   int n_tok, void* stream);
+int cg_tok_bn_lin_fwd(float* R, float* T2, double* stat_out, const float* T1, const double* stat_in,
+                      const float* gamma, const float* beta, float eps, float* mean_out,
+                      float* invstd_out, float* running_mean, float* running_var, float momentum,
+                      const float* W2, const float* b2, int n_tok, void* stream);
+int cg_tok_bn_res_fwd(float* Y, const float* T2, const double* stat_in, const float* gamma,
+                      const float* beta, float eps, float* mean_out, float* invstd_out,
+                      float* running_mean, float* running_var, float momentum, const float* X,
+                      int n_tok, void* stream);
+int cg_tok_bn_bwd_stats(double* stat_out, const float* dY, const float* T2, const float* mean,
+                        const float* invstd, int n_tok, void* stream);
+int cg_tok_bwd_mid(float* G1, double* stat_out, float* wpart, float* dgamma2, float* dbeta2,
+                   const float* dY, const float* T2, const float* R, const float* T1,
+                   const double* stat_in, const float* mean2, const float* invstd2,
+                   const float* gamma2, const float* W2, const float* mean1, const float* invstd1,
+                   int n_tok, void* stream);
+int cg_tok_bwd_in(float* dX, float* wpart, float* dgamma1, float* dbeta1, const float* G1,
+                  const float* T1, const float* X, const float* dY, const double* stat_in,
+                  const float* mean1, const float* invstd1, const float* gamma1, const float* W1,
+                  int n_tok, void* stream);
+int cg_tok_wgrad_reduce(float* dW2, float* dW1, const float* wpart2, const float* wpart1, int n_tok,
+                        void* stream);
+
+/*
  * Fused multi-tensor Adam with amsgrad (torch.optim.Adam(..., betas=(0.5,0.9),
  * amsgrad=True), GAN_functions.py:223-225, stepped at :339-340,:409) over one
  * flat parameter arena: p, g, m, v, vmax are arrays of n floats.

@@ -100,6 +100,76 @@ class CpuOps:
             self.bn_bwd(dX[sl], dY[sl], X[sl], None if Y is None else Y[sl], None if PM is None else PM[sl],
                         mean[s], invstd[s], gamma, dgamma, dbeta, accumulate or s > 0, slope)
 
+    # -- latent ResidualBlock on tokens (cg_tok_*) ------------------------------------------------
+    # The partial-sum buffers of the device kernels are an implementation detail; here `stat` carries the two
+    # column sums in its first 32 entries and `wpart` the whole weight gradient in its first 256.
+    TOK_BLOCK = 128
+
+    def tok_blocks(self, n_tok):
+        return (n_tok + self.TOK_BLOCK - 1) // self.TOK_BLOCK
+
+    @staticmethod
+    def _put_stats(stat, a, b):
+        stat.view(-1)[:16] = a.double().sum(0)
+        stat.view(-1)[16:32] = (a.double() * b.double()).sum(0)
+
+    def _tok_bn_cols(self, stat, n, eps, mean, invstd, rmean, rvar, momentum, dtype):
+        s = stat.view(-1)
+        mu = s[:16] / n
+        var = (s[16:32] / n - mu * mu).clamp_min(0)
+        mean.copy_(mu.to(dtype))
+        invstd.copy_((1.0 / torch.sqrt(var + eps)).to(dtype))
+        if rmean is not None:
+            rmean.copy_((1 - momentum) * rmean + momentum * mean)
+        if rvar is not None:
+            rvar.copy_((1 - momentum) * rvar + momentum * (var * (n / max(n - 1, 1))).to(dtype))
+
+    def tok_lin_fwd(self, T1, stat_out, X, W, b):
+        T1.copy_(X @ W.t() + b)
+        self._put_stats(stat_out, T1, T1)
+
+    def tok_bn_lin_fwd(self, R, T2, stat_out, T1, stat_in, gamma, beta, mean, invstd, rmean, rvar, W2, b2, eps=1e-5,
+                       momentum=0.1):
+        self._tok_bn_cols(stat_in, T1.shape[0], eps, mean, invstd, rmean, rvar, momentum, T1.dtype)
+        R.copy_(torch.relu((T1 - mean) * invstd * gamma + beta))
+        T2.copy_(R @ W2.t() + b2)
+        self._put_stats(stat_out, T2, T2)
+
+    def tok_bn_res_fwd(self, Y, T2, stat_in, gamma, beta, mean, invstd, rmean, rvar, X, eps=1e-5, momentum=0.1):
+        self._tok_bn_cols(stat_in, T2.shape[0], eps, mean, invstd, rmean, rvar, momentum, T2.dtype)
+        Y.copy_(X + ((T2 - mean) * invstd * gamma + beta))
+
+    def tok_bn_bwd_stats(self, stat_out, dY, T2, mean, invstd):
+        self._put_stats(stat_out, dY, (T2 - mean) * invstd)
+
+    @staticmethod
+    def _tok_bn_bwd(g, xh, stat, n, invstd, gamma, dgamma, dbeta):
+        s = stat.view(-1)
+        gbar, gxbar = (s[:16] / n).to(g.dtype), (s[16:32] / n).to(g.dtype)
+        if dbeta is not None:
+            dbeta += s[:16].to(g.dtype)
+        if dgamma is not None:
+            dgamma += s[16:32].to(g.dtype)
+        return invstd * gamma * (g - gbar - xh * gxbar)
+
+    def tok_bwd_mid(self, G1, stat_out, wpart, dgamma2, dbeta2, dY, T2, R, T1, stat_in, mean2, invstd2, gamma2, W2,
+                    mean1, invstd1):
+        n = dY.shape[0]
+        dT2 = self._tok_bn_bwd(dY, (T2 - mean2) * invstd2, stat_in, n, invstd2, gamma2, dgamma2, dbeta2)
+        wpart.view(-1)[:256] = (dT2.t() @ R).reshape(-1)
+        G1.copy_((dT2 @ W2) * (R > 0).to(R.dtype))
+        self._put_stats(stat_out, G1, (T1 - mean1) * invstd1)
+
+    def tok_bwd_in(self, dX, wpart, dgamma1, dbeta1, G1, T1, X, dY, stat_in, mean1, invstd1, gamma1, W1):
+        n = dY.shape[0]
+        dT1 = self._tok_bn_bwd(G1, (T1 - mean1) * invstd1, stat_in, n, invstd1, gamma1, dgamma1, dbeta1)
+        wpart.view(-1)[:256] = (dT1.t() @ X).reshape(-1)
+        dX.copy_(dY + dT1 @ W1)
+
+    def tok_wgrad_reduce(self, dW2, dW1, wpart2, wpart1, n_tok):
+        dW2 += wpart2.view(-1)[:256].view_as(dW2)
+        dW1 += wpart1.view(-1)[:256].view_as(dW1)
+
     def bn_eval(self, Y, X, gamma, beta, rmean, rvar, slope, eps=1e-5):
         h = (X - rmean) * (1.0 / torch.sqrt(rvar + eps)) * gamma + beta
         Y.copy_(torch.where(h > 0, h, h * slope))

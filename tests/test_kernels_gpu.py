@@ -221,6 +221,44 @@ def test_bn_segments(ops, b, nseg, order, N):
         close(g, e, 1e-4, f"bn_bwd_seg {w}")
 
 
+@pytest.mark.parametrize("n_tok", [8192, 16 * 37, 128, 48])
+def test_token_residual_block(ops, n_tok):
+    """Fused latent ResidualBlock kernels (forward and backward) against their float64 CPU restatement."""
+    c64 = CpuOps(torch.float64)
+    d = lambda t: t.double()  # noqa: E731
+    X = rnd(n_tok, 16, seed=1)
+    W1, W2 = rnd(16, 16, seed=2) * 0.4, rnd(16, 16, seed=3) * 0.4
+    b1, b2 = rnd(16, seed=4), rnd(16, seed=5)
+    g1, be1, g2, be2 = rnd(16, seed=6) + 1.5, rnd(16, seed=7), rnd(16, seed=8) + 1.5, rnd(16, seed=9)
+    rm, rv = rnd(16, seed=10), rnd(16, seed=11).abs() + 0.5
+    dY = rnd(n_tok, 16, seed=12)
+    nb = ops.tok_blocks(n_tok)
+
+    def run(o, cast, Z, Zd):
+        T1, R, T2, Y, G1, dX = (Z(n_tok, 16) for _ in range(6))
+        st = [Zd(nb * 32) for _ in range(4)]
+        wp2, wp1 = Z(nb * 256), Z(nb * 256)
+        m1, i1, m2, i2 = Z(16), Z(16), Z(16), Z(16)
+        rm1, rv1, rm2, rv2 = cast(rm).clone(), cast(rv).clone(), cast(rm).clone(), cast(rv).clone()
+        dW1, dW2 = Z(16, 16) + 1, Z(16, 16) + 1
+        dg1, db1, dg2, db2 = Z(16) + 1, Z(16) + 1, Z(16) + 1, Z(16) + 1
+        x, w1, w2 = cast(X), cast(W1), cast(W2)
+        o.tok_lin_fwd(T1, st[0], x, w1, cast(b1))
+        o.tok_bn_lin_fwd(R, T2, st[1], T1, st[0], cast(g1), cast(be1), m1, i1, rm1, rv1, w2, cast(b2))
+        o.tok_bn_res_fwd(Y, T2, st[1], cast(g2), cast(be2), m2, i2, rm2, rv2, x)
+        dy = cast(dY)
+        o.tok_bn_bwd_stats(st[2], dy, T2, m2, i2)
+        o.tok_bwd_mid(G1, st[3], wp2, dg2, db2, dy, T2, R, T1, st[2], m2, i2, cast(g2), w2, m1, i1)
+        o.tok_bwd_in(dX, wp1, dg1, db1, G1, T1, x, dy, st[3], m1, i1, cast(g1), w1)
+        o.tok_wgrad_reduce(dW2, dW1, wp2, wp1, n_tok)
+        return dict(T1=T1, R=R, T2=T2, Y=Y, m1=m1, i1=i1, m2=m2, i2=i2, rm1=rm1, rv1=rv1, rm2=rm2, rv2=rv2, G1=G1, dX=dX,
+                    dW1=dW1, dW2=dW2, dg1=dg1, db1=db1, dg2=dg2, db2=db2)
+    exp = run(c64, d, lambda *s: torch.zeros(*s, dtype=torch.float64), lambda *s: torch.zeros(*s, dtype=torch.float64))
+    got = run(ops, dev, lambda *s: torch.zeros(*s, device="cuda"), lambda *s: torch.zeros(*s, dtype=torch.float64, device="cuda"))
+    for k in exp:
+        close(got[k], exp[k], 2e-4 if k in ("G1", "dX", "dW1", "dW2", "dg1", "db1", "dg2", "db2") else 3e-5, f"tok {k}")
+
+
 def test_bn_bwd_matches_autograd():
     """The CPU restatement of the BatchNorm backward itself against torch autograd (float64)."""
     M, N = 24, 10
