@@ -489,6 +489,8 @@ extern "C" int cg_gemm(float* C, int ldc, const void* A, int lda, const void* B,
   static const int split_choices[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
   int best = 2, best_splits = 1;
   double best_cost = 1e300;
+  double tile_bias[3] = {1.0, 1.0, 1.0};
+  if (const char* f = getenv("CGRNA_GEMM_BIAS")) sscanf(f, "%lf,%lf,%lf", &tile_bias[0], &tile_bias[1], &tile_bias[2]);
   for (int c = 0; c < 3; ++c) {
     const long tiles = (long)((M + cands[c].bm - 1) / cands[c].bm) * ((N + cands[c].bn - 1) / cands[c].bn);
     for (int sp : split_choices) {
@@ -498,6 +500,7 @@ extern "C" int cg_gemm(float* C, int ldc, const void* A, int lda, const void* B,
       const int slabs = (nk + sp - 1) / sp;
       double cost = slabs * (n * cands[c].S > cands[c].L ? n * cands[c].S : cands[c].L) + cands[c].P * (accumulate ? 1.5 : 1.0);
       if (sp > 1) cost += 6.0 + (sp + 1) * (double)per / 4.0e6;
+      cost *= tile_bias[c];
       if (cost < best_cost) { best_cost = cost; best = c; best_splits = sp; }
     }
   }

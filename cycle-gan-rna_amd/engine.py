@@ -854,24 +854,36 @@ class StepEngine:
     def d_step(self, mouse, human, mouse_cat, human_cat, noise):
         b = mouse.shape[0]
         assert human.shape[0] == b and b <= self.max_b
-        self._begin_opt(self.arena_d, self.lr_d)
         if self._d_scales_b != b:
             lam = float(self.cfg["lambda_gp"])
             self.d_scales.copy_(torch.tensor([-1.0 / b, 1.0 / b, lam / b] * 2, dtype=torch.float64))
             self._d_scales_b = b
-        self._run_parts("d", b, (mouse, human, mouse_cat, human_cat), noise,
-                        [self._d_compute, self._d_comm, self._d_update])
+        ins = (mouse, human, mouse_cat, human_cat)
+        if not self.sync.enabled:
+            self._begin_opt(self.arena_d, self.lr_d)
+            self._run_parts("d", b, ins, noise, [("graph", self._d_gen), ("graph", self._d_critics),
+                                                 ("graph", self._d_update)])
+        else:
+            # several ranks: the gradient all-reduce of this step is left in flight and the critics' Adam update is
+            # applied just before the critics are used next - after the generators' forward of the next step, which
+            # does not need them - so the transfer hides behind that forward
+            pend = self._d_pending_lr is not None
+            self._run_parts("d", b, ins, noise, [("graph", self._d_gen),
+                                                 ("eager", self._d_wait_pending if pend else None),
+                                                 ("graph", self._d_apply_pending if pend else None),
+                                                 ("graph", self._d_critics), ("eager", self._d_launch_comm)])
 
     def _run_parts(self, kind, b, tensors, noise, parts):
-        """A step is a list of parts: device work, a collective, device work, ...  On one rank the collectives are
-        no-ops and the whole list is one HIP graph; with several ranks every device part is a graph of its own and
-        the collectives between them are issued eagerly."""
-        first, rest = parts[0], parts[1:]
+        """A step is a list of parts, ("graph", fn) for device work and ("eager", fn) for collectives and host
+        work; a part whose fn is None is skipped.  The first part receives (tensors..., noise).  On one rank the
+        whole list is captured as one HIP graph; with several ranks every device part is a graph of its own and
+        the eager parts run between the replays."""
         graphs = self.use_graphs and b == self.max_b
+        parts = [(k, fn) for k, fn in parts if fn is not None]
 
         def whole(*a):
-            first(*a)
-            for fn in rest:
+            parts[0][1](*a)
+            for _, fn in parts[1:]:
                 fn()
         if not self.sync.enabled:
             if graphs:
@@ -879,26 +891,51 @@ class StepEngine:
             else:
                 whole(*tensors, noise)
             return
-        for i, fn in enumerate(parts):
-            if i % 2 == 1:
-                fn()                                       # collective
-            elif not graphs:
-                fn(*tensors, noise) if i == 0 else fn()
-            elif i == 0:
-                self._graphed(f"{kind}{i}", fn, tensors, noise)
+        for i, (k, fn) in enumerate(parts):
+            if i == 0:
+                if graphs:
+                    self._graphed(f"{kind}:{fn.__name__}", fn, tensors, noise)
+                else:
+                    fn(*tensors, noise)
+            elif k == "eager" or not graphs:
+                fn()
             else:
-                self._graphed(f"{kind}{i}", lambda _noise, fn=fn: fn(), (), noise)
+                self._graphed(f"{kind}:{fn.__name__}", lambda _noise, fn=fn: fn(), (), noise)
 
-    def _d_compute(self, mouse, human, mouse_cat, human_cat, noise):
-        ops, cfg = self.ops, self.cfg
-        b = mouse.shape[0]
-        self.arena_d.g.zero_()
+    # Deferred critic update (several ranks only).
+    _d_pending_lr = None
+
+    def _d_wait_pending(self):
+        self.sync.wait()
+        self._begin_opt(self.arena_d, self._d_pending_lr)
+
+    def _d_apply_pending(self):
+        self._adam(self.arena_d)
+
+    def _d_launch_comm(self):
+        self.sync.launch(self.arena_d.g)
+        self._d_pending_lr = self.lr_d
+
+    def flush(self):
+        """Apply a critic update that is still in flight (several ranks); call before reading critic parameters."""
+        if self._d_pending_lr is not None:
+            self._d_wait_pending()
+            self._adam(self.arena_d)
+            self._d_pending_lr = None
+
+    def _d_gen(self, mouse, human, mouse_cat, human_cat, noise):
         out = {}
 
         def gen(which, x, lab):
             out[which] = self.gen_a[which].forward(x, lab, noise)
         self._two(lambda: gen("g_m2h", mouse, mouse_cat), lambda: gen("g_h2m", human, human_cat))
-        fake_human, fake_mouse = out["g_m2h"], out["g_h2m"]
+        self._d_state = (mouse, human, mouse_cat, human_cat, noise, out["g_m2h"], out["g_h2m"])
+
+    def _d_critics(self):
+        ops, cfg = self.ops, self.cfg
+        mouse, human, mouse_cat, human_cat, noise, fake_human, fake_mouse = self._d_state
+        b = mouse.shape[0]
+        self.arena_d.g.zero_()
 
         def critic_fwd(name, real, real_lab, fake, fake_lab, s0):
             ds = self.dstack[name]
@@ -919,14 +956,10 @@ class StepEngine:
                    lambda: self.dstack["d_h"].backward_params(b, (-1.0 / b, 1.0 / b)),
                    lambda: self.dstack["d_h"].gp_backward(b, 2, cfg["lambda_gp"], self.red, S_DH_REAL + 2))
         self.arena_d.g.add_(self.arena_d.g2)
-
-    def _d_comm(self):
-        self.sync.launch(self.arena_d.g)
-        self.sync.wait()
+        ops.sum_parts(self.d_tot, self.red, self.d_slots, self.d_scales)
 
     def _d_update(self):
         self._adam(self.arena_d)
-        self.ops.sum_parts(self.d_tot, self.red, self.d_slots, self.d_scales)
 
     def d_losses(self):
         t = self.d_tot.cpu()
@@ -939,17 +972,25 @@ class StepEngine:
     def g_step(self, mouse, human, mouse_cat, human_cat, noise):
         b = mouse.shape[0]
         self._begin_opt(self.arena_g, self.lr_g)
+        multi = self.sync.enabled and self._d_pending_lr is not None
         self._run_parts("g", b, (mouse, human, mouse_cat, human_cat), noise,
-                        [self._g_forward, self._g_loss_comm, self._g_backward, self._g_grad_comm, self._g_update])
+                        [("graph", self._g_first),
+                         ("eager", self._d_wait_pending if multi else None),      # the critics are needed from here on
+                         ("graph", self._d_apply_pending if multi else None),
+                         ("eager", self._d_clear_pending if multi else None),
+                         ("graph", self._g_rest),
+                         ("eager", self._g_loss_comm if self.sync.enabled else None),
+                         ("graph", self._g_backward),
+                         ("eager", self._g_grad_comm if self.sync.enabled else None),
+                         ("graph", self._g_update)])
 
-    def _g_forward(self, mouse, human, mouse_cat, human_cat, noise):
-        ops, cfg = self.ops, self.cfg
-        b = mouse.shape[0]
-        gm, gh = self.g_mouse, self.g_human
+    def _d_clear_pending(self):
+        self._d_pending_lr = None
+
+    def _g_first(self, mouse, human, mouse_cat, human_cat, noise):
         self.arena_g.g.zero_()
         A, Bp = self.gen_a["g_m2h"], self.gen_a["g_h2m"]
-        Rm, Rh = self.gen_b["g_h2m"], self.gen_b["g_m2h"]
-        red, o = self.red, {}
+        o = {}
         # Forward, in the reference's call order (:344-372).  Each pair below is independent and may run on two
         # streams; the human-side member comes first, as in the reference, so a sequential run draws its noise in
         # the reference's order.
@@ -957,6 +998,15 @@ class StepEngine:
         def fwd(key, p, x, lab):
             o[key] = p.forward(x, lab, noise)
         self._two(lambda: fwd("fh", A, mouse, mouse_cat), lambda: fwd("fm", Bp, human, human_cat))
+        self._g_state = (mouse, human, mouse_cat, human_cat, o, noise)
+
+    def _g_rest(self):
+        ops = self.ops
+        mouse, human, mouse_cat, human_cat, o, noise = self._g_state
+        b = mouse.shape[0]
+        A, Bp = self.gen_a["g_m2h"], self.gen_a["g_h2m"]
+        Rm, Rh = self.gen_b["g_h2m"], self.gen_b["g_m2h"]
+        red = self.red
         fake_human, fake_mouse = o["fh"], o["fm"]
 
         adv_masks = {}
@@ -991,7 +1041,6 @@ class StepEngine:
                                    "m_real", "m_fake", S_FM_M, Bp, S_KL_M))
         if self.sync.enabled:
             ops.sum_parts(self.g_tot, red, self.g_slots, self.g_ones)
-        self._g_state = (mouse, human, mouse_cat, human_cat, o)
 
     def _g_loss_comm(self):
         # every rank must derive the same loss scales: the local loss sums are replaced by their sum over ranks
@@ -999,7 +1048,7 @@ class StepEngine:
 
     def _g_backward(self):
         ops, cfg, red = self.ops, self.cfg, self.red
-        mouse, human, mouse_cat, human_cat, o = self._g_state
+        mouse, human, mouse_cat, human_cat, o, _ = self._g_state
         fake_human, fake_mouse, recov_mouse, recov_human = o["fh"], o["fm"], o["rm"], o["rh"]
         b = mouse.shape[0]
         gm, gh = self.g_mouse, self.g_human
@@ -1080,4 +1129,5 @@ class StepEngine:
         return out
 
     def state_dict(self, name):
+        self.flush()
         return self.nets[name].state_dict()

@@ -35,6 +35,7 @@ def _worker(rank, world, port, out):
     assert eng.sync.enabled and eng.sync.world == world
     torch.manual_seed(100 + rank)
     res = eng.iteration(0, xm[sl], xh[sl], lm[sl], lh[sl], HostReplayNoise("cpu"))
+    eng.flush()      # apply the critic update that is still in flight
     torch.save(dict(d=eng.arena_d.p.clone(), g=eng.arena_g.p.clone(), coef=eng.coef.clone(), g_loss=res["g_loss"]),
                os.path.join(out, f"rank{rank}.pt"))
     dist.destroy_process_group()

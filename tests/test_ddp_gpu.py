@@ -41,6 +41,7 @@ def _worker(rank, world, port, out, graphs):
         res = eng.iteration(i, xm[sl].cuda(), xh[sl].cuda(), lm[sl, None].cuda(), lh[sl, None].cuda(), noise)
     assert not graphs or all(g["graph"] is not None for g in eng._graphs.values())
     torch.cuda.synchronize()
+    eng.flush()      # apply the critic update that is still in flight
     torch.save(dict(d=eng.arena_d.p.cpu(), g=eng.arena_g.p.cpu(), coef=eng.coef.cpu(), g_loss=res["g_loss"]),
                os.path.join(out, f"rank{rank}_{int(graphs)}.pt"))
     dist.destroy_process_group()
