@@ -106,19 +106,18 @@ def main():
     from cycle_gan_rna_amd.engine import StepEngine
     from cycle_gan_rna_amd.noise import DeviceNoise
     from cycle_gan_rna_amd.ops import HipOps
-    from oracle import cyclegan_oracle as O          # synthetic data + init recipe only
-    from oracle import init_params
+    from cycle_gan_rna_amd import synthetic as S
 
     G, B = a.genes, a.batch
-    cfg = O.default_config(preprocess_type="log_normalized", batch_size=B)
-    nets = init_params.build_nets(G, G, [N_TYPES], cfg, seed=0)          # same weights on every rank
+    cfg = S.default_config(preprocess_type="log_normalized", batch_size=B)
+    nets = S.random_networks(G, G, [N_TYPES], cfg, seed=0)               # same weights on every rank
     n_cells = 16 * B
-    xm, lm = O.synthetic_expression(n_cells, G, N_TYPES, seed=1234 + 2 * rank)
-    xh, lh = O.synthetic_expression(n_cells, G, N_TYPES, seed=1235 + 2 * rank)
-    cm, ch = O.centroid_table(xm, lm, N_TYPES), O.centroid_table(xh, lh, N_TYPES)
+    xm, lm = S.synthetic_expression(n_cells, G, N_TYPES, seed=1234 + 2 * rank, device=dev)
+    xh, lh = S.synthetic_expression(n_cells, G, N_TYPES, seed=1235 + 2 * rank, device=dev)
+    cm, ch = S.centroid_table(xm, lm, N_TYPES), S.centroid_table(xh, lh, N_TYPES)
     ops = HipOps(dev, precision="bf16" if a.dtype == "bf16" else "fp32")
     eng = StepEngine(nets, cfg, cm, ch, ops, B)
-    xm, xh, lm, lh = xm.to(dev), xh.to(dev), lm[:, None].to(dev), lh[:, None].to(dev)
+    lm, lh = lm[:, None].contiguous(), lh[:, None].contiguous()
     noise = DeviceNoise(dev, seed=1 + rank, default_generator=True)
     if not a.sequential:
         eng.enable_concurrency()
