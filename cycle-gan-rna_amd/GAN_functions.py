@@ -550,8 +550,18 @@ def train_enhanced_cycle_gan(g_m2h, g_h2m, d_m, d_h, mouse_adata, human_adata,
     eng = StepEngine({k: m.state_dict() for k, m in modules.items()}, config,
                      table(mouse_centroids, mouse_tensor.shape[1]), table(human_centroids, human_tensor.shape[1]),
                      ops, config['batch_size'])
-    noise = (HostReplayNoise(device) if config.get('noise', 'device') == 'host_replay'
-             else DeviceNoise(device, seed=int(torch.empty((), dtype=torch.int64).random_().item() % (2 ** 31))))
+    if config.get('noise', 'device') == 'host_replay':
+        noise = HostReplayNoise(device)          # the reference's CPU draws, call by call (parity runs)
+    else:
+        # noise drawn in HBM from the default HIP generator (seeded from torch's global CPU generator, so
+        # torch.manual_seed still decides the run); the step is then replayed as HIP graphs and its independent
+        # branches run on side streams
+        noise = DeviceNoise(device, seed=int(torch.empty((), dtype=torch.int64).random_().item() % (2 ** 31)),
+                            default_generator=True)
+        if config.get('concurrent_streams', True):
+            eng.enable_concurrency()
+        if config.get('hip_graphs', True):
+            eng.enable_graphs()
     metrics = {k: [] for k in ('g_loss', 'd_m_loss', 'd_h_loss', 'fake_human_var', 'fake_mouse_var', 'cycle_loss',
                                'celltype_loss', 'fm_loss', 'kl_loss', 'current_lr')}
     timestamp = datetime.now().strftime("%Y%m%d_%H%M")

@@ -155,6 +155,41 @@ def test_train_function_against_reference(tag):
     assert float((got - ref_final["values"].double()).norm() / upd_ref.norm()) <= 0.35
 
 
+def test_train_function_default_mode_replays_graphs():
+    """Default mode of the drop-in loop (noise drawn in HBM): the step runs as HIP graphs on several streams.  With
+    the same seed, a run that launches every kernel eagerly on one stream gives the same metrics bit for bit."""
+    from cycle_gan_rna_amd import GAN_functions as F
+    from oracle import cyclegan_oracle as O
+    fx = torch.load(os.path.join(GOLD, "function_level.pt"), weights_only=True)["one_iter_epochs"]
+    gm, gh, N = fx["g_mouse"], fx["g_human"], fx["N"]
+    xm, _ = O.synthetic_expression(N, gm, 12, seed=3)
+    xh, _ = O.synthetic_expression(N, gh, 12, seed=4)
+    lm, lh = O.balanced_labels(N, 12, 5), O.balanced_labels(N, 12, 6)
+    names = [f"type{i:02d}" for i in range(12)]
+    cat = np.concatenate([lm.numpy(), lh.numpy()])[:, None]
+    res = {}
+    cwd = os.getcwd()
+    for mode in ("fast", "plain"):
+        cfg = dict(fx["cfg"], device="cuda", progress=False, epochs=4, hip_graphs=mode == "fast",
+                   concurrent_streams=mode == "fast")
+        mods = build_modules(gm, gh, cfg, fx["init_seed"])
+        with tempfile.TemporaryDirectory() as tmp:
+            os.chdir(tmp)
+            try:
+                torch.manual_seed(11)
+                np.random.seed(0)
+                metrics, _ = F.train_enhanced_cycle_gan(
+                    *mods, Obs([names[i] for i in lm.tolist()]), Obs([names[i] for i in lh.tolist()]), xm, xh, cat,
+                    xh.numpy()[:, :2], TwoCol(), dict(enumerate(names)), cfg, torch.device("cuda:0"))
+            finally:
+                os.chdir(cwd)
+        assert all(np.isfinite(v).all() for v in metrics.values())
+        res[mode] = (metrics, mods[0].state_dict()["encoder.0.weight"].cpu())
+    for k in res["fast"][0]:
+        assert res["fast"][0][k] == res["plain"][0][k], k
+    assert torch.equal(res["fast"][1], res["plain"][1])
+
+
 def _oracle_state(module):
     return {k: v.detach().cpu().clone() for k, v in module.state_dict().items()}
 
