@@ -37,6 +37,7 @@ BUFFER_SUFFIXES = ("running_mean", "running_var", "num_batches_tracked")
 (S_DM_REAL, S_DM_FAKE, S_DM_GP, S_DH_REAL, S_DH_FAKE, S_DH_GP,
  S_ADV_H, S_ADV_M, S_CYC_M, S_CYC_H, S_CT_H, S_CT_M, S_FM_H, S_FM_M, S_KL_H, S_KL_M, N_SLOTS) = range(17)
 MAX_PARTS = 1024
+PIN_SLOTS = 64          # staging slots for the {lr, step} uploads of optimizer steps in flight
 
 
 def _pad4(n):
@@ -676,8 +677,123 @@ class CriticStack:
             ops.embed_scatter(G["embeddings.0.weight"], self.demb2[:b], self.lab[sl], False)
 
 
+class EngineBase:
+    """Execution plumbing shared by the training engines: optimizer step on a flat arena, HIP-graph capture and
+    replay of a step, independent branches on side streams.  A subclass provides self.ops, self.nets (name -> Net),
+    self.max_b and self.sync."""
+
+    use_graphs = False
+    concurrent = False
+    _pin = None
+
+    # ---- two-stream concurrency ------------------------------------------------------
+    def enable_concurrency(self):
+        """Run the mouse->human and human->mouse halves of a step (and the two critics) on two HIP
+        streams.  They are independent between a few join points, and most kernels of one half
+        leave much of the chip idle at batch 512, so the halves overlap.  Only for noise that is
+        drawn on the device: the order of draws then differs from the reference's call order."""
+        self.sides = [torch.cuda.Stream(device=self.ops.device) for _ in range(3)]
+        for st in self.sides:
+            self.ops.prepare_stream(st)
+        self.ops.prepare_stream(torch.cuda.current_stream(self.ops.device))
+        self.concurrent = True
+
+    def _many(self, *branches):
+        """Run independent branches side by side: the first on the current stream, the others on side streams
+        that start from what the current stream has queued so far; then join.  The host calls them in the order
+        given, so noise is drawn in the same order as in a sequential run."""
+        if not self.concurrent:
+            for fn in branches:
+                fn()
+            return
+        main = torch.cuda.current_stream(self.ops.device)
+        used = self.sides[:len(branches) - 1]
+        for st in used:
+            st.wait_stream(main)
+        branches[0]()
+        for st, fn in zip(used, branches[1:]):
+            with torch.cuda.stream(st):
+                fn()
+        for st in used:
+            main.wait_stream(st)
+
+    def _two(self, first, second):
+        self._many(first, second)
+
+    # ---- optimizer ---------------------------------------------------------------
+    def set_lr(self, lr):
+        """LRDecayScheduler writes one lr into all three optimizers (:244-246)."""
+        self.lr_g = lr
+        self.lr_d = lr
+
+    def _begin_opt(self, arena, lr):
+        """Host side of an optimizer step: advance the step count and upload {lr, step}
+        (the Adam kernel reads them from device memory, so a captured step can be replayed).
+        The upload is asynchronous and the host may run many steps ahead of the device, so each upload has
+        its own pinned staging slot; a slot is reused only after the copy that read it has completed."""
+        arena.step += 1
+        if self.ops.device.type != "cuda":
+            arena.lr_step.copy_(torch.tensor([lr, float(arena.step)], dtype=torch.float64))
+            return
+        if self._pin is None:
+            self._pin = dict(buf=torch.zeros(PIN_SLOTS, 2, dtype=torch.float64, pin_memory=True),
+                             done=[None] * PIN_SLOTS, next=0)
+        ring = self._pin
+        i = ring["next"]
+        ring["next"] = (i + 1) % PIN_SLOTS
+        if ring["done"][i] is not None:
+            ring["done"][i].synchronize()
+        host = ring["buf"][i]
+        host[0], host[1] = lr, float(arena.step)
+        arena.lr_step.copy_(host, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.ops.device))
+        ring["done"][i] = ev
+
+    def _adam(self, arena):
+        self.ops.adam(arena.p, arena.g, arena.m, arena.v, arena.vmax, arena.lr_step, 0.5, 0.9, 1e-8)
+
+    # ---- HIP graphs ------------------------------------------------------------------
+    def enable_graphs(self):
+        """Capture the device work of the critic step and of the generator step into HIP
+        graphs (first full-size call runs eagerly, the second is captured, later ones are
+        replayed).  Needs a noise source that draws into fixed device buffers
+        (noise.DeviceNoise); ragged batches stay eager.  With several ranks the collectives stay outside the
+        graphs (see _run_parts)."""
+        self._graphs = {}
+        self.use_graphs = True
+
+    def _graphed(self, kind, body, tensors, noise):
+        st = self._graphs.setdefault(kind, dict(calls=0, graph=None, static=None, nbt=None))
+        if st["static"] is None:
+            st["static"] = [torch.empty_like(t) for t in tensors]
+        for dst, src in zip(st["static"], tensors):
+            dst.copy_(src)
+        st["calls"] += 1
+        if st["calls"] == 1:
+            body(*st["static"], noise)
+            return
+        if st["graph"] is None:
+            before = {n: dict(net.nbt) for n, net in self.nets.items()}
+            g = torch.cuda.CUDAGraph()
+            # thread-local capture mode: helper threads of the process (a collective backend's progress thread, for
+            # one) may keep making HIP calls while this thread captures
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                body(*st["static"], noise)
+            st["graph"] = g
+            st["nbt"] = {n: {k: net.nbt[k] - before[n][k] for k in net.nbt} for n, net in self.nets.items()}
+            g.replay()
+            return
+        st["graph"].replay()
+        for n, d in st["nbt"].items():
+            for k, v in d.items():
+                if v:
+                    self.nets[n].nbt[k] += v
+
+
+
 # --------------------------------------------------------------------------- #
-class StepEngine:
+class StepEngine(EngineBase):
     """State of a training run on one device + the two halves of an iteration."""
 
     def __init__(self, nets: Dict[str, Dict[str, torch.Tensor]], cfg: dict, mouse_centroids, human_centroids, ops,
@@ -729,49 +845,12 @@ class StepEngine:
         self.var_out = Z(2)
         self.var_ws = Z(max((max(gm, gh) + 31) // 32, 1), dtype=torch.float64)
         self._d_scales_b = None
-        self._pin = None
-        self.use_graphs = False
-        self.concurrent = False
         self.d_feat2 = Z(B, 256)
         from .ddp import GradSync
         self.sync = GradSync(ops.device)
         self.g_tot = Z(10, dtype=torch.float64)
         self.g_slots = ops.to_device(torch.arange(S_ADV_H, S_ADV_H + 10, dtype=torch.int32))
         self.g_ones = ops.to_device(torch.ones(10, dtype=torch.float64))
-
-    # ---- two-stream concurrency ------------------------------------------------------
-    def enable_concurrency(self):
-        """Run the mouse->human and human->mouse halves of a step (and the two critics) on two HIP
-        streams.  They are independent between a few join points, and most kernels of one half
-        leave much of the chip idle at batch 512, so the halves overlap.  Only for noise that is
-        drawn on the device: the order of draws then differs from the reference's call order."""
-        self.sides = [torch.cuda.Stream(device=self.ops.device) for _ in range(3)]
-        for st in self.sides:
-            self.ops.prepare_stream(st)
-        self.ops.prepare_stream(torch.cuda.current_stream(self.ops.device))
-        self.concurrent = True
-
-    def _many(self, *branches):
-        """Run independent branches side by side: the first on the current stream, the others on side streams
-        that start from what the current stream has queued so far; then join.  The host calls them in the order
-        given, so noise is drawn in the same order as in a sequential run."""
-        if not self.concurrent:
-            for fn in branches:
-                fn()
-            return
-        main = torch.cuda.current_stream(self.ops.device)
-        used = self.sides[:len(branches) - 1]
-        for st in used:
-            st.wait_stream(main)
-        branches[0]()
-        for st, fn in zip(used, branches[1:]):
-            with torch.cuda.stream(st):
-                fn()
-        for st in used:
-            main.wait_stream(st)
-
-    def _two(self, first, second):
-        self._many(first, second)
 
     @staticmethod
     def _critic_noise(noise, b, nseg, draw_order=None, alpha_before=None, first=None):
@@ -791,64 +870,6 @@ class StepEngine:
                 alpha = noise.rand((b, 1))
             pairs[sg] = (noise.keep((b, 1024), 0.3), noise.keep((b, 512), 0.3))
         return (torch.cat([pairs[i][0] for i in range(nseg)]), torch.cat([pairs[i][1] for i in range(nseg)]), alpha)
-
-    # ---- optimizer ---------------------------------------------------------------
-    def set_lr(self, lr):
-        """LRDecayScheduler writes one lr into all three optimizers (:244-246)."""
-        self.lr_g = lr
-        self.lr_d = lr
-
-    def _begin_opt(self, arena, lr):
-        """Host side of an optimizer step: advance the step count and upload {lr, step}
-        (the Adam kernel reads them from device memory, so a captured step can be replayed)."""
-        arena.step += 1
-        if self._pin is None:
-            pin = self.ops.device.type == "cuda"
-            self._pin = {id(self.arena_d): torch.zeros(2, dtype=torch.float64, pin_memory=pin),
-                         id(self.arena_g): torch.zeros(2, dtype=torch.float64, pin_memory=pin)}
-        host = self._pin[id(arena)]
-        host[0], host[1] = lr, float(arena.step)
-        arena.lr_step.copy_(host, non_blocking=True)
-
-    def _adam(self, arena):
-        self.ops.adam(arena.p, arena.g, arena.m, arena.v, arena.vmax, arena.lr_step, 0.5, 0.9, 1e-8)
-
-    # ---- HIP graphs ------------------------------------------------------------------
-    def enable_graphs(self):
-        """Capture the device work of the critic step and of the generator step into HIP
-        graphs (first full-size call runs eagerly, the second is captured, later ones are
-        replayed).  Needs a noise source that draws into fixed device buffers
-        (noise.DeviceNoise); ragged batches stay eager.  With several ranks the collectives stay outside the
-        graphs (see _run_parts)."""
-        self._graphs = {}
-        self.use_graphs = True
-
-    def _graphed(self, kind, body, tensors, noise):
-        st = self._graphs.setdefault(kind, dict(calls=0, graph=None, static=None, nbt=None))
-        if st["static"] is None:
-            st["static"] = [torch.empty_like(t) for t in tensors]
-        for dst, src in zip(st["static"], tensors):
-            dst.copy_(src)
-        st["calls"] += 1
-        if st["calls"] == 1:
-            body(*st["static"], noise)
-            return
-        if st["graph"] is None:
-            before = {n: dict(net.nbt) for n, net in self.nets.items()}
-            g = torch.cuda.CUDAGraph()
-            # thread-local capture mode: helper threads of the process (a collective backend's progress thread, for
-            # one) may keep making HIP calls while this thread captures
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                body(*st["static"], noise)
-            st["graph"] = g
-            st["nbt"] = {n: {k: net.nbt[k] - before[n][k] for k in net.nbt} for n, net in self.nets.items()}
-            g.replay()
-            return
-        st["graph"].replay()
-        for n, d in st["nbt"].items():
-            for k, v in d.items():
-                if v:
-                    self.nets[n].nbt[k] += v
 
     # ---- critic step (:322-340) -------------------------------------------------------
     def d_step(self, mouse, human, mouse_cat, human_cat, noise):

@@ -79,3 +79,31 @@ def build_nets(g_mouse, g_human, vocab_sizes, cfg, seed):
     nets['d_m'] = discriminator_state(g_mouse, vocab_sizes)
     nets['d_h'] = discriminator_state(g_human, vocab_sizes)
     return nets
+
+
+def cwgan_generator_state(x_dim, vocab_sizes, nb_numeric, z_dim):
+    """Generator of the conditional WGAN (/root/reference/cWGAN_my.ipynb cell 1): embeddings of width
+    min(50, vocab), then Linear-BatchNorm pairs of widths 256, 512, 1024 and the output Linear."""
+    sd = OrderedDict()
+    for i, vs in enumerate(vocab_sizes):
+        _put(sd, f"embeddings.{i}", nn.Embedding(vs, min(50, vs)))
+    in_dim = z_dim + sum(min(50, vs) for vs in vocab_sizes) + nb_numeric
+    for li, h in enumerate((256, 512, 1024)):
+        _put(sd, f"network.{3 * li}", nn.Linear(in_dim, h))
+        _put(sd, f"network.{3 * li + 1}", nn.BatchNorm1d(h))
+        in_dim = h
+    _put(sd, "network.9", nn.Linear(in_dim, x_dim))
+    return sd
+
+
+def cwgan_discriminator_state(x_dim, vocab_sizes, nb_numeric):
+    """Critic of the conditional WGAN (cWGAN_my.ipynb cell 2, use_neg_detector=False)."""
+    sd = OrderedDict()
+    for i, vs in enumerate(vocab_sizes):
+        _put(sd, f"embeddings.{i}", nn.Embedding(vs, min(50, vs)))
+    in_dim = x_dim + sum(min(50, vs) for vs in vocab_sizes) + nb_numeric
+    for li, h in enumerate((1024, 512, 256)):
+        _put(sd, f"main_network.{3 * li}", nn.Linear(in_dim, h))
+        in_dim = h
+    _put(sd, "main_network.9", nn.Linear(in_dim, 1))
+    return sd

@@ -1,0 +1,125 @@
+"""Conditional WGAN-GP of cWGAN_my.ipynb on the MI355X: the HIP engine (cwgan_engine.py) against the CPU oracle
+on the same seeds, inputs and noise, and against the golden vectors captured from the notebook's own cells.
+
+Tolerances (float32 on both sides, different summation orders): first iteration rel <= 1e-4 on the losses and the
+generated cells; later iterations <= 5e-3 / 3e-2 (Adam amplifies rounding differences step by step)."""
+import os
+
+import pytest
+import torch
+
+from oracle import cwgan_oracle as W
+from oracle import cyclegan_oracle as O
+from oracle import init_params
+from tests.helpers import rel, update_rel_l2
+from tests.test_cwgan_host import CFG, GOLD, cwgan_problem
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from cycle_gan_rna_amd.ops import HipOps
+    return HipOps("cuda:0")
+
+
+def run_both(ops, x_dim, vocab, batch, iters, cfg=CFG):
+    from cycle_gan_rna_amd.cwgan_engine import CwganEngine
+    from cycle_gan_rna_amd.noise import HostReplayNoise
+    g, d, x, cat, num = cwgan_problem(x_dim, vocab, batch)
+    tr = W.CwganOracleTrainer(g, d, cfg)
+    torch.manual_seed(11)
+    exp = [tr.iteration(x, cat, num) for _ in range(iters)]
+    eng = CwganEngine(g, d, cfg, ops, batch)
+    noise = HostReplayNoise(ops.device)
+    dx, dcat, dnum = x.cuda(), cat.cuda(), num.cuda()
+    torch.manual_seed(11)
+    got = []
+    for _ in range(iters):
+        eng.iteration(dx, dcat, dnum, noise)
+        got.append(dict(eng.losses(), fake=eng.fake.cpu().clone()))
+    torch.cuda.synchronize()
+    return (g, d), tr, eng, exp, got
+
+
+@pytest.mark.parametrize("x_dim,vocab,batch", [(48, [3, 12], 16), (300, [3, 12], 24), (37, [5], 13), (512, [12], 64)])
+def test_iterations_match_oracle(ops, x_dim, vocab, batch):
+    init, tr, eng, exp, got = run_both(ops, x_dim, vocab, batch, iters=4)
+    for i, (e, g) in enumerate(zip(exp, got)):
+        tol = 1e-4 if i == 0 else 5e-3
+        for k in ("d_loss", "gp", "g_loss", "g_loss_main"):
+            assert rel(g[k], e[k], 0.5) <= tol, (i, k, g[k], e[k])
+        assert rel(g["fake"], e["fake"]) <= (1e-4 if i == 0 else 3e-2), (i, rel(g["fake"], e["fake"]))
+    for name, ref, start in (("g", tr.G, init[0]), ("d", tr.D, init[1])):
+        sd = eng.state_dict(name)
+        for k, v in sd.items():
+            if k.endswith("num_batches_tracked"):
+                assert int(v) == int(ref[k]), k
+            elif k.endswith(("running_mean", "running_var")):
+                assert rel(v, ref[k]) <= 5e-3, k
+            elif k in ("network.0.bias", "network.3.bias", "network.6.bias"):
+                continue          # a bias feeding a BatchNorm: zero gradient, random walk on rounding noise
+            elif float((ref[k].detach() - start[k]).abs().max()) == 0.0:
+                assert rel(v, ref[k]) <= 1e-6, k
+            else:
+                assert update_rel_l2(v, ref[k].detach(), start[k]) <= 3e-1, (name, k)
+
+
+def test_module_level_golden(ops):
+    """The notebook's own outputs (recorded noise replayed): generated cells, the three critic calls, the penalty
+    and the critic's parameter gradients of one critic update."""
+    from cycle_gan_rna_amd.cwgan_engine import CwganEngine
+    from cycle_gan_rna_amd.noise import RecordedNoise
+    fx = torch.load(GOLD, weights_only=True)["module"]
+    torch.manual_seed(fx["init_seed"])
+    g = init_params.cwgan_generator_state(fx["x_dim"], fx["vocab"], 0, fx["z_dim"])
+    d = init_params.cwgan_discriminator_state(fx["x_dim"], fx["vocab"], 0)
+    b = fx["x"].shape[0]
+    eng = CwganEngine(g, d, dict(CFG, lr=0.0), ops, b)          # lr 0: the update leaves the weights in place
+    x, cat, num = fx["x"].cuda(), fx["cat"].cuda(), torch.zeros(b, 0).cuda()
+    eng.d_step(x, cat, num, RecordedNoise([fx["z"]] + list(fx["noise"]), ops.device))
+    torch.cuda.synchronize()
+    assert rel(eng.crit.x_seg(1, b).cpu(), fx["fake"]) <= 1e-4
+    val = eng.crit.val[:3 * b].cpu()
+    assert rel(val[:b], fx["real_v"]) <= 1e-4 and rel(val[b:2 * b], fx["fake_v"]) <= 1e-4
+    ref_d = float(-fx["real_v"].mean() + fx["fake_v"].mean() + 10 * fx["gp"])
+    assert rel(eng.d_loss_now(), ref_d, 0.5) <= 1e-4 and rel(eng.losses()["gp"], fx["gp"]) <= 1e-4
+    G = eng.nets["d"].G
+    floor = 1e-3 * max(float(sp["values"].abs().max()) for sp in fx["d_grads"].values())
+    for k, sp in fx["d_grads"].items():
+        assert rel(G[k].cpu().reshape(-1)[::sp["stride"]], sp["values"], floor) <= 0.5, k
+
+
+def test_graph_replay_and_streams_equal_eager(ops):
+    from cycle_gan_rna_amd.cwgan_engine import CwganEngine
+    from cycle_gan_rna_amd.noise import DeviceNoise
+    g, d, x, cat, num = cwgan_problem(64, [3, 12], 32)
+    dx, dcat, dnum = x.cuda(), cat.cuda(), num.cuda()
+    finals = []
+    for graphs, streams in ((False, False), (True, False), (False, True), (True, True)):
+        eng = CwganEngine(g, d, CFG, ops, 32)
+        if streams:
+            eng.enable_concurrency()
+        if graphs:
+            eng.enable_graphs()
+        noise = DeviceNoise(ops.device, seed=7, default_generator=True)
+        for _ in range(4):
+            noise.begin_step()
+            eng.iteration(dx, dcat, dnum, noise)
+        torch.cuda.synchronize()
+        finals.append((eng.arena_d.p.clone(), eng.arena_g.p.clone(), eng.losses()))
+    for dp, gp_, lo in finals[1:]:
+        assert torch.equal(finals[0][0], dp) and torch.equal(finals[0][1], gp_)
+        assert lo == finals[0][2]
+
+
+def test_eval_generation_uses_running_statistics(ops):
+    from cycle_gan_rna_amd.cwgan_engine import CwganEngine
+    g, d, x, cat, num = cwgan_problem(48, [3, 12], 16)
+    eng = CwganEngine(g, d, CFG, ops, 16)
+    z = torch.randn(16, 64, generator=torch.Generator().manual_seed(1))
+    out = eng.generate(z.cuda(), cat.cuda(), num.cuda(), train=False).cpu()
+    with torch.no_grad():
+        ref = W.generator_forward({k: v.clone() for k, v in g.items()}, z, cat, num, 10000, train=False)
+    assert rel(out, ref) <= 1e-4
+    assert rel(out.sum(1), torch.full((16,), 10000.0)) <= 1e-4
