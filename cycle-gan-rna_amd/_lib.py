@@ -81,11 +81,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("CGRNA_LIB", LIB_PATH)     # tuning aid: a differently built copy of the same library
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} is missing: build it with `python cycle-gan-rna_amd/build.py` "
+            f"{path} is missing: build it with `python cycle-gan-rna_amd/build.py` "
             "(this package has no CPU or PyTorch fallback for its kernels)")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (argtypes, restype) in SIGNATURES.items():
         fn = getattr(lib, name)      # AttributeError if the symbol is not exported
         fn.argtypes = argtypes

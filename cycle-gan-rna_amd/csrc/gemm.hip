@@ -16,6 +16,17 @@
 #include <cstdlib>
 #include "common.h"
 
+#ifndef CG_PF_SMALL
+#define CG_PF_SMALL 2
+#define CG_PF_MID 2
+#define CG_PF_BIG 2
+#endif
+#ifndef CG_KW_SMALL
+#define CG_KW_SMALL 2
+#define CG_KW_MID 2
+#define CG_KW_BIG 1
+#endif
+
 namespace {
 
 struct GemmArgs {
@@ -31,21 +42,44 @@ struct GemmArgs {
   int tiles_n;
   int kt_per_split;   // K slabs handled by one blockIdx.y (split-K); all of them when gridDim.y == 1
   float* ws;          // split-K: partial results [gridDim.y][M][N]
+  unsigned a_bytes, b_bytes;   // footprints of A and B in memory (hardware range check of the buffer loads)
 };
 
 constexpr int BK = 32;
 
-// Guarded 4-element load along the contiguous dimension.
+// Slabs of global loads kept in flight ahead of the MFMAs, per block tile (register stages).
+constexpr int prefetch_depth(int bm, int bn) { return bm * bn <= 64 * 64 ? CG_PF_SMALL : (bm * bn <= 128 * 64 ? CG_PF_MID : CG_PF_BIG); }
+// Wave groups per workgroup of the float32 kernel (see gemm_f32_kernel).
+constexpr int kwaves(int bm, int bn) { return bm * bn <= 64 * 64 ? CG_KW_SMALL : (bm * bn <= 128 * 64 ? CG_KW_MID : CG_KW_BIG); }
+constexpr int prefetch_depth_bf16(int bm, int bn) { return bm * bn <= 64 * 64 ? 2 : 1; }
+
+// Operand tiles are read with buffer loads: the hardware range check returns 0 for an offset at or beyond the
+// operand's footprint, so rows and k values outside the matrix are requested at OOB_OFF and need no branch; what a
+// 16-byte load picks up past the end of a row (the next row's elements) is cleared when the tile goes to LDS.
+// Branch-free loads let the compiler count them (s_waitcnt vmcnt(n)) and keep several slabs in flight.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB_OFF = 0x80000000u;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+
+// Four elements along the contiguous dimension starting at byte offset `off` (element index c0 of climit).
 template <bool VEC>
-__device__ __forceinline__ f32x4 load4(const float* p, bool outer_ok, int c0, int climit) {
-  f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  if (!outer_ok) return v;
-  if (VEC && c0 + 3 < climit) {
-    v = *reinterpret_cast<const f32x4*>(p);
-  } else {
+__device__ __forceinline__ f32x4 bload4(__amdgpu_buffer_rsrc_t rs, unsigned off, bool ok, int c0, int climit) {
+  if (VEC) return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? off : OOB_OFF, 0, 0));
+  f32x4 v;
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (c0 + e < climit) v[e] = p[e];
+  for (int e = 0; e < 4; ++e)
+    v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, (ok && c0 + e < climit) ? off + 4 * e : OOB_OFF, 0, 0));
+  return v;
+}
+
+template <bool VEC>
+__device__ __forceinline__ f32x4 clip4(f32x4 v, int c0, int climit) {
+  if (VEC) {
+#pragma unroll
+    for (int e = 1; e < 4; ++e) v[e] = c0 + e < climit ? v[e] : 0.f;
   }
   return v;
 }
@@ -53,38 +87,41 @@ __device__ __forceinline__ f32x4 load4(const float* p, bool outer_ok, int c0, in
 // Stage registers for one operand tile of ROWS x BK.
 //  k-major: element (r,k) = ptr[(row0+r)*ld + k0+k]
 //  m-major: element (r,k) = ptr[(k0+k)*ld + row0+r]
-template <int ROWS, bool MMAJ, bool VEC>
+template <int ROWS, bool MMAJ, bool VEC, int NT>
 struct Stager {
-  static constexpr int NV = ROWS * BK / 4 / 256;  // float4 per thread
+  static constexpr int NV = ROWS * BK / 4 / NT;  // float4 per thread
+  static_assert(NV >= 1 && NV * NT * 4 == ROWS * BK, "tile does not divide over the workgroup");
   f32x4 v[NV];
+  int k0s;   // first k of the slab held in v
 
-  __device__ __forceinline__ void load(const float* ptr, int ld, int row0, int nrows, int k0, int K) {
+  __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, int ld, int row0, int nrows, int k0, int K) {
     const int t = threadIdx.x;
+    k0s = k0;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-      const int idx = t + 256 * j;
+      const int idx = t + NT * j;
       if (!MMAJ) {
         const int r = idx / (BK / 4), kq = idx % (BK / 4);
         const int row = row0 + r, k = k0 + 4 * kq;
-        v[j] = load4<VEC>(ptr + (size_t)row * ld + k, row < nrows, k, K);
+        v[j] = bload4<VEC>(rs, ((unsigned)row * ld + k) * 4u, row < nrows && k < K, k, K);
       } else {
         const int k = idx / (ROWS / 4), rq = idx % (ROWS / 4);
         const int row = row0 + 4 * rq, kk = k0 + k;
-        v[j] = load4<VEC>(ptr + (size_t)kk * ld + row, kk < K, row, nrows);
+        v[j] = bload4<VEC>(rs, ((unsigned)kk * ld + row) * 4u, kk < K && row < nrows, row, nrows);
       }
     }
   }
-  __device__ __forceinline__ void store(float* s) const {
+  __device__ __forceinline__ void store(float* s, int row0, int nrows, int K) const {
     const int t = threadIdx.x;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-      const int idx = t + 256 * j;
+      const int idx = t + NT * j;
       if (!MMAJ) {
         const int r = idx / (BK / 4), kq = idx % (BK / 4);
-        *reinterpret_cast<f32x4*>(s + r * (BK + 4) + 4 * kq) = v[j];
+        *reinterpret_cast<f32x4*>(s + r * (BK + 4) + 4 * kq) = clip4<VEC>(v[j], k0s + 4 * kq, K);
       } else {
         const int k = idx / (ROWS / 4), rq = idx % (ROWS / 4);
-        *reinterpret_cast<f32x4*>(s + k * (ROWS + 4) + 4 * rq) = v[j];
+        *reinterpret_cast<f32x4*>(s + k * (ROWS + 4) + 4 * rq) = clip4<VEC>(v[j], row0 + 4 * rq, nrows);
       }
     }
   }
@@ -148,16 +185,18 @@ template <int ROWS, bool MMAJ, bool VEC>
 struct StagerH {
   static constexpr int NV = ROWS * BKH / 4 / 256;   // float4 per thread (8 for 128 rows, 4 for 64)
   f32x4 v[NV];
+  int k0s;
 
-  __device__ __forceinline__ void load(const float* ptr, int ld, int row0, int nrows, int k0, int K) {
+  __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, int ld, int row0, int nrows, int k0, int K) {
     const int t = threadIdx.x;
+    k0s = k0;
     if (!MMAJ) {
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
         const int idx = t + 256 * j;
         const int r = idx / (BKH / 4), kq = idx % (BKH / 4);
         const int row = row0 + r, k = k0 + 4 * kq;
-        v[j] = load4<VEC>(ptr + (size_t)row * ld + k, row < nrows, k, K);
+        v[j] = bload4<VEC>(rs, ((unsigned)row * ld + k) * 4u, row < nrows && k < K, k, K);
       }
     } else {
       // micro-tile mt = 4 k-rows x 4 rows; v[4*u + i] = k-row 4*kq+i of micro-tile u
@@ -168,29 +207,32 @@ struct StagerH {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int kk = k0 + 4 * kq + i, row = row0 + 4 * rq;
-          v[4 * u + i] = load4<VEC>(ptr + (size_t)kk * ld + row, kk < K, row, nrows);
+          v[4 * u + i] = bload4<VEC>(rs, ((unsigned)kk * ld + row) * 4u, kk < K && row < nrows, row, nrows);
         }
       }
     }
   }
-  __device__ __forceinline__ void store(u16* s) const {
+  __device__ __forceinline__ void store(u16* s, int row0, int nrows, int K) const {
     const int t = threadIdx.x;
     if (!MMAJ) {
 #pragma unroll
       for (int j = 0; j < NV; ++j) {
         const int idx = t + 256 * j;
         const int r = idx / (BKH / 4), kq = idx % (BKH / 4);
-        *reinterpret_cast<uint2*>(s + r * LDH + 4 * kq) = pack4(v[j][0], v[j][1], v[j][2], v[j][3]);
+        const f32x4 w = clip4<VEC>(v[j], k0s + 4 * kq, K);
+        *reinterpret_cast<uint2*>(s + r * LDH + 4 * kq) = pack4(w[0], w[1], w[2], w[3]);
       }
     } else {
 #pragma unroll
       for (int u = 0; u < NV / 4; ++u) {
         const int idx = t + 256 * u;
         const int kq = idx / (ROWS / 4), rq = idx % (ROWS / 4);
+        f32x4 w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w[i] = clip4<VEC>(v[4 * u + i], row0 + 4 * rq, nrows);
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-          *reinterpret_cast<uint2*>(s + (4 * rq + c) * LDH + 4 * kq) =
-              pack4(v[4 * u][c], v[4 * u + 1][c], v[4 * u + 2][c], v[4 * u + 3][c]);
+          *reinterpret_cast<uint2*>(s + (4 * rq + c) * LDH + 4 * kq) = pack4(w[0][c], w[1][c], w[2][c], w[3][c]);
       }
     }
   }
@@ -217,48 +259,54 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  StagerH<BM, A_MMAJ, VEC> sa;
-  StagerH<BN, B_MMAJ, VEC> sb;
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc(g.A, g.a_bytes), rsB = make_rsrc(g.B, g.b_bytes);
+  constexpr int D = prefetch_depth_bf16(BM, BN);   // register stages of global loads in flight (see gemm_f32_kernel)
+  StagerH<BM, A_MMAJ, VEC> sa[D];
+  StagerH<BN, B_MMAJ, VEC> sb[D];
   const int nk_all = (g.K + BKH - 1) / BKH;
   const int kt0 = blockIdx.y * g.kt_per_split;
   const int nk = min(nk_all, kt0 + g.kt_per_split);
 
-  sa.load(g.A, g.lda, bm, g.M, kt0 * BKH, g.K);
-  sb.load(g.B, g.ldb, bn, g.N, kt0 * BKH, g.K);
-  sa.store(smem);
-  sb.store(smem + A_ELEMS);
+  const int klim = min(g.K, nk * BKH);   // straight-line loop body, see gemm_f32_kernel
+#pragma unroll
+  for (int s = 0; s < D; ++s) {
+    sa[s].load(rsA, g.lda, bm, g.M, (kt0 + s) * BKH, klim);
+    sb[s].load(rsB, g.ldb, bn, g.N, (kt0 + s) * BKH, klim);
+  }
+  sa[0].store(smem, bm, g.M, klim);
+  sb[0].store(smem + A_ELEMS, bn, g.N, klim);
   __syncthreads();
 
   int cur = 0;
-  for (int kt = kt0; kt < nk; ++kt) {
-    if (kt + 1 < nk) {
-      sa.load(g.A, g.lda, bm, g.M, (kt + 1) * BKH, g.K);
-      sb.load(g.B, g.ldb, bn, g.N, (kt + 1) * BKH, g.K);
-    }
-    const u16* As = smem + cur * (A_ELEMS + B_ELEMS);
-    const u16* Bs = As + A_ELEMS;
+  for (int base = kt0; base < nk; base += D) {
 #pragma unroll
-    for (int ks = 0; ks < BKH / 32; ++ks) {
-      bf16x8 a[TM], b[TN];
+    for (int s = 0; s < D; ++s) {
+      const int kt = base + s;
+      sa[s].load(rsA, g.lda, bm, g.M, (kt + D) * BKH, klim);
+      sb[s].load(rsB, g.ldb, bn, g.N, (kt + D) * BKH, klim);
+      const u16* As = smem + cur * (A_ELEMS + B_ELEMS);
+      const u16* Bs = As + A_ELEMS;
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-        a[i] = *reinterpret_cast<const bf16x8*>(As + (wm + 16 * i + lr) * LDH + 32 * ks + 8 * lg);
+      for (int ks = 0; ks < BKH / 32; ++ks) {
+        bf16x8 a[TM], b[TN];
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-        b[j] = *reinterpret_cast<const bf16x8*>(Bs + (wn + 16 * j + lr) * LDH + 32 * ks + 8 * lg);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
+          a[i] = *reinterpret_cast<const bf16x8*>(As + (wm + 16 * i + lr) * LDH + 32 * ks + 8 * lg);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-    if (kt + 1 < nk) {
+          b[j] = *reinterpret_cast<const bf16x8*>(Bs + (wn + 16 * j + lr) * LDH + 32 * ks + 8 * lg);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      }
       u16* nxt = smem + (cur ^ 1) * (A_ELEMS + B_ELEMS);
-      sa.store(nxt);
-      sb.store(nxt + A_ELEMS);
+      sa[(s + 1) % D].store(nxt, bm, g.M, klim);
+      sb[(s + 1) % D].store(nxt + A_ELEMS, bn, g.N, klim);
+      __syncthreads();
+      cur ^= 1;
     }
-    __syncthreads();
-    cur ^= 1;
   }
 
   // 16x16 accumulator: col = lane & 15, row = 4 * (lane >> 4) + reg
@@ -280,8 +328,12 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgs g) {
     }
 }
 
-template <int BM, int BN, bool TA, bool TB, bool VEC>
-__global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
+// KW wave groups of four waves share a block tile: every group multiplies its own 1/KW of each K slab into its own
+// accumulators (two or more waves per SIMD hide each other's LDS and barrier waits even when the workgroup has
+// the CU to itself); the groups' accumulators are added through LDS, in group order, before the epilogue.
+template <int BM, int BN, bool TA, bool TB, bool VEC, int KW>
+__global__ void __launch_bounds__(256 * KW) gemm_f32_kernel(GemmArgs g) {
+  constexpr int NT = 256 * KW;
   constexpr int TM = BM / 64, TN = BN / 64;
   constexpr bool A_MMAJ = TA, B_MMAJ = !TB;
   constexpr int A_ELEMS = A_MMAJ ? BK * (BM + 4) : BM * (BK + 4);
@@ -292,9 +344,12 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
   int tile_m, tile_n;
   tile_coords(tile, (g.M + BM - 1) / BM, g.tiles_n, tile_m, tile_n);
   const int bm = tile_m * BM, bn = tile_n * BN;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, kg = threadIdx.x >> 8;
   const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
   const int li = lane & 31, lh = lane >> 5;
+  constexpr int CG = BK / 8 / KW;   // groups of eight k per slab handled by one wave group
+  static_assert(CG * KW * 8 == BK, "K slab does not divide over the wave groups");
+  static_assert(KW == 1 || TM * TN * 16 * 256 * (KW - 1) <= 2 * (A_ELEMS + B_ELEMS), "accumulator exchange does not fit in LDS");
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -304,64 +359,101 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  Stager<BM, A_MMAJ, VEC> sa;
-  Stager<BN, B_MMAJ, VEC> sb;
+  // Global loads run D slabs ahead of the MFMAs (D register stages; LDS stays double-buffered): a workgroup that
+  // has a CU to itself - most launches of this workload have at most one workgroup per CU - must cover the
+  // global-load latency with its own work, and one slab of MFMAs is shorter than that latency.
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc(g.A, g.a_bytes), rsB = make_rsrc(g.B, g.b_bytes);
+  constexpr int D = prefetch_depth(BM, BN);
+  Stager<BM, A_MMAJ, VEC, NT> sa[D];
+  Stager<BN, B_MMAJ, VEC, NT> sb[D];
   const int nk_all = (g.K + BK - 1) / BK;
   const int kt0 = blockIdx.y * g.kt_per_split;
   const int nk = min(nk_all, kt0 + g.kt_per_split);
 
-  sa.load(g.A, g.lda, bm, g.M, kt0 * BK, g.K);
-  sb.load(g.B, g.ldb, bn, g.N, kt0 * BK, g.K);
-  sa.store(smem);
-  sb.store(smem + A_ELEMS);
+  // The loop body is straight-line: every load, LDS store and barrier is unconditional, so the compiler can count
+  // the loads in flight (a conditional load or store makes it drain them all).  The trip count is rounded up to a
+  // multiple of D; slabs at or beyond klim read as zeros (the range-checked loads) and add nothing.
+  const int klim = min(g.K, nk * BK);
+#pragma unroll
+  for (int s = 0; s < D; ++s) {
+    sa[s].load(rsA, g.lda, bm, g.M, (kt0 + s) * BK, klim);
+    sb[s].load(rsB, g.ldb, bn, g.N, (kt0 + s) * BK, klim);
+  }
+  sa[0].store(smem, bm, g.M, klim);
+  sb[0].store(smem + A_ELEMS, bn, g.N, klim);
   __syncthreads();
 
   int cur = 0;
-  for (int kt = kt0; kt < nk; ++kt) {
-    if (kt + 1 < nk) {
-      sa.load(g.A, g.lda, bm, g.M, (kt + 1) * BK, g.K);
-      sb.load(g.B, g.ldb, bn, g.N, (kt + 1) * BK, g.K);
-    }
-    const float* As = smem + cur * (A_ELEMS + B_ELEMS);
-    const float* Bs = As + A_ELEMS;
+  for (int base = kt0; base < nk; base += D) {
 #pragma unroll
-    for (int c = 0; c < BK / 8; ++c) {
-      float a[TM][4], b[TN][4];
+    for (int s = 0; s < D; ++s) {
+      const int kt = base + s;
+      // stage s went to LDS one step ago: refill it with the slab D ahead
+      sa[s].load(rsA, g.lda, bm, g.M, (kt + D) * BK, klim);
+      sb[s].load(rsB, g.ldb, bn, g.N, (kt + D) * BK, klim);
+      const float* As = smem + cur * (A_ELEMS + B_ELEMS);
+      const float* Bs = As + A_ELEMS;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        if (!A_MMAJ) {
-          f32x4 t = *reinterpret_cast<const f32x4*>(As + (wm + 32 * i + li) * (BK + 4) + 8 * c + 4 * lh);
-          a[i][0] = t[0]; a[i][1] = t[1]; a[i][2] = t[2]; a[i][3] = t[3];
-        } else {
+      for (int cc = 0; cc < CG; ++cc) {
+        const int c = kg * CG + cc;
+        float a[TM][4], b[TN][4];
 #pragma unroll
-          for (int s = 0; s < 4; ++s) a[i][s] = As[(8 * c + 4 * lh + s) * (BM + 4) + wm + 32 * i + li];
+        for (int i = 0; i < TM; ++i) {
+          if (!A_MMAJ) {
+            f32x4 t = *reinterpret_cast<const f32x4*>(As + (wm + 32 * i + li) * (BK + 4) + 8 * c + 4 * lh);
+            a[i][0] = t[0]; a[i][1] = t[1]; a[i][2] = t[2]; a[i][3] = t[3];
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[i][q] = As[(8 * c + 4 * lh + q) * (BM + 4) + wm + 32 * i + li];
+          }
         }
-      }
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        if (!B_MMAJ) {
-          f32x4 t = *reinterpret_cast<const f32x4*>(Bs + (wn + 32 * j + li) * (BK + 4) + 8 * c + 4 * lh);
-          b[j][0] = t[0]; b[j][1] = t[1]; b[j][2] = t[2]; b[j][3] = t[3];
-        } else {
+        for (int j = 0; j < TN; ++j) {
+          if (!B_MMAJ) {
+            f32x4 t = *reinterpret_cast<const f32x4*>(Bs + (wn + 32 * j + li) * (BK + 4) + 8 * c + 4 * lh);
+            b[j][0] = t[0]; b[j][1] = t[1]; b[j][2] = t[2]; b[j][3] = t[3];
+          } else {
 #pragma unroll
-          for (int s = 0; s < 4; ++s) b[j][s] = Bs[(8 * c + 4 * lh + s) * (BN + 4) + wn + 32 * j + li];
+            for (int q = 0; q < 4; ++q) b[j][q] = Bs[(8 * c + 4 * lh + q) * (BN + 4) + wn + 32 * j + li];
+          }
         }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
       }
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
-    }
-    if (kt + 1 < nk) {
       float* nxt = smem + (cur ^ 1) * (A_ELEMS + B_ELEMS);
-      sa.store(nxt);
-      sb.store(nxt + A_ELEMS);
+      sa[(s + 1) % D].store(nxt, bm, g.M, klim);
+      sb[(s + 1) % D].store(nxt + A_ELEMS, bn, g.N, klim);
+      __syncthreads();
+      cur ^= 1;
+    }
+  }
+
+  if (KW > 1) {   // add the wave groups' accumulators through LDS (the K loop ended on a barrier)
+    float* xs = smem + ((kg > 0 ? kg - 1 : 0) * 4 + wave) * (TM * TN * 16 * 64) + lane;
+    if (kg > 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) xs[((i * TN + j) * 16 + r) * 64] = acc[i][j][r];
     }
     __syncthreads();
-    cur ^= 1;
+    if (kg > 0) return;
+#pragma unroll
+    for (int q = 1; q < KW; ++q)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            acc[i][j][r] += xs[(q - 1) * 4 * (TM * TN * 16 * 64) + ((i * TN + j) * 16 + r) * 64];
   }
 
   // epilogue: 32x32 accumulator, col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -397,24 +489,71 @@ __global__ void __launch_bounds__(256) gemm_f32_kernel(GemmArgs g) {
     }
 }
 
-// Combine the split-K partials in split order and apply the epilogue of cg_gemm.
+// Combine the split-K partials in split order and apply the epilogue of cg_gemm.  VEC4: four consecutive columns
+// per thread with 16-byte accesses (N, every leading dimension and every base address a multiple of four floats).
+template <bool VEC4>
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(GemmArgs g, int splits) {
-  const size_t total = (size_t)g.M * g.N;
+  constexpr int W = VEC4 ? 4 : 1;
+  const size_t total = (size_t)g.M * g.N / W;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-    const int m = (int)(i / g.N), n = (int)(i % g.N);
-    float h = g.bias ? g.bias[n] : 0.f;
-    for (int k = 0; k < splits; ++k) h += g.ws[(size_t)k * total + i];
-    float* cp = g.C + (size_t)m * g.ldc + n;
-    if (g.epi == CG_EPI_NONE) {
-      *cp = g.accumulate ? *cp + h : h;
-    } else if (g.epi == CG_EPI_LEAKY) {
-      float pm = h > 0.f ? 1.f : g.slope;
-      if (g.E) pm *= g.E[(size_t)m * g.lde + n];
-      *cp = h * pm;
-      if (g.aux) g.aux[(size_t)m * g.ldaux + n] = pm;
-    } else {
-      *cp = h * g.E[(size_t)m * g.lde + n];
+    const size_t e0 = i * W;
+    const int m = (int)(e0 / g.N), n = (int)(e0 % g.N);
+    float h[W];
+#pragma unroll
+    for (int e = 0; e < W; ++e) h[e] = g.bias ? g.bias[n + e] : 0.f;
+    for (int k = 0; k < splits; ++k) {
+      const float* p = g.ws + (size_t)k * g.M * g.N + e0;
+      if (VEC4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+        for (int e = 0; e < W; ++e) h[e] += v[e];
+      } else {
+        h[0] += p[0];
+      }
     }
+    float* cp = g.C + (size_t)m * g.ldc + n;
+    float out[W], pmv[W];
+    if (g.epi == CG_EPI_NONE) {
+      if (g.accumulate) {
+        if (VEC4) {
+          const f32x4 c = *reinterpret_cast<const f32x4*>(cp);
+#pragma unroll
+          for (int e = 0; e < W; ++e) out[e] = c[e] + h[e];
+        } else {
+          out[0] = cp[0] + h[0];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < W; ++e) out[e] = h[e];
+      }
+    } else {
+      float ev[W];
+      if (g.E) {
+        const float* ep = g.E + (size_t)m * g.lde + n;
+        if (VEC4) {
+          const f32x4 t = *reinterpret_cast<const f32x4*>(ep);
+#pragma unroll
+          for (int e = 0; e < W; ++e) ev[e] = t[e];
+        } else {
+          ev[0] = ep[0];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < W; ++e) ev[e] = 1.f;
+      }
+#pragma unroll
+      for (int e = 0; e < W; ++e) {
+        pmv[e] = g.epi == CG_EPI_LEAKY ? (h[e] > 0.f ? 1.f : g.slope) * ev[e] : ev[e];
+        out[e] = h[e] * pmv[e];
+      }
+      if (g.epi == CG_EPI_LEAKY && g.aux) {
+        float* ap = g.aux + (size_t)m * g.ldaux + n;
+        if (VEC4) *reinterpret_cast<f32x4*>(ap) = f32x4{pmv[0], pmv[W > 1 ? 1 : 0], pmv[W > 2 ? 2 : 0], pmv[W > 3 ? 3 : 0]};
+        else ap[0] = pmv[0];
+      }
+    }
+    if (VEC4) *reinterpret_cast<f32x4*>(cp) = f32x4{out[0], out[W > 1 ? 1 : 0], out[W > 2 ? 2 : 0], out[W > 3 ? 3 : 0]};
+    else cp[0] = out[0];
   }
 }
 
@@ -427,15 +566,16 @@ int launch_f32(const GemmArgs& g, int transA, int transB, bool vec, hipStream_t 
   const int nk = (g.K + bk - 1) / bk;
   a.kt_per_split = (nk + splits - 1) / splits;
   splits = (nk + a.kt_per_split - 1) / a.kt_per_split;   // no empty split
-  dim3 grid(tm * tn, splits), block(256);
+  constexpr int KW = HALF ? 1 : kwaves(BM, BN);
+  dim3 grid(tm * tn, splits), block(256 * KW);
 #define CG_LAUNCH(TA, TB)                                                                    \
   do {                                                                                       \
     if (HALF) {                                                                              \
       if (vec) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, TA, TB, true>), grid, block, 0, st, a);   \
       else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, TA, TB, false>), grid, block, 0, st, a);      \
     } else {                                                                                 \
-      if (vec) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, true>), grid, block, 0, st, a);    \
-      else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, false>), grid, block, 0, st, a);       \
+      if (vec) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, true, KW>), grid, block, 0, st, a);    \
+      else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, false, KW>), grid, block, 0, st, a);       \
     }                                                                                        \
   } while (0)
   if (!transA && transB) CG_LAUNCH(false, true);
@@ -445,9 +585,12 @@ int launch_f32(const GemmArgs& g, int transA, int transB, bool vec, hipStream_t 
 #undef CG_LAUNCH
   if (splits > 1) {
     const size_t total = (size_t)g.M * g.N;
-    int blocks = (int)((total + 255) / 256);
-    if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, g, splits);
+    auto al = [](const void* p, int ld) { return p == nullptr || (((uintptr_t)p % 16 == 0) && ld % 4 == 0); };
+    const bool v4 = g.N % 4 == 0 && al(g.C, g.ldc) && al(g.E, g.lde) && al(g.aux, g.ldaux) && al(g.ws, 4);
+    int blocks = (int)((total / (v4 ? 4 : 1) + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    if (v4) hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(blocks), dim3(256), 0, st, g, splits);
+    else hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(blocks), dim3(256), 0, st, g, splits);
   }
   return cg_launch_status();
 }
@@ -465,15 +608,17 @@ extern "C" int cg_gemm(float* C, int ldc, const void* A, int lda, const void* B,
   if (epi != CG_EPI_NONE && accumulate) return CG_ERR_BAD_ARG;
   const int a_rows = transA ? K : M, a_cols = transA ? M : K;
   const int b_rows = transB ? N : K, b_cols = transB ? K : N;
-  (void)a_rows; (void)b_rows;
   if (lda < a_cols || ldb < b_cols || ldc < N) return CG_ERR_BAD_ARG;
   if (E && lde < N) return CG_ERR_BAD_ARG;
   if (aux && ldaux < N) return CG_ERR_BAD_ARG;
   if (dtype != CG_F32 && dtype != CG_BF16) return CG_ERR_UNSUPPORTED;
   const bool half = dtype == CG_BF16;
   hipStream_t st = (hipStream_t)stream;
+  const size_t a_bytes = K ? ((size_t)(a_rows - 1) * lda + a_cols) * sizeof(float) : 0;
+  const size_t b_bytes = K ? ((size_t)(b_rows - 1) * ldb + b_cols) * sizeof(float) : 0;
+  if (a_bytes >= OOB_OFF || b_bytes >= OOB_OFF) return CG_ERR_UNSUPPORTED;   // 32-bit buffer offsets
   GemmArgs g{(const float*)A, (const float*)B, C, bias, E, aux, M, N, K, lda, ldb, ldc, lde, ldaux,
-             epi, accumulate, slope, 0, 1 << 30, (float*)workspace};
+             epi, accumulate, slope, 0, 1 << 30, (float*)workspace, (unsigned)a_bytes, (unsigned)b_bytes};
   const bool vec = (((uintptr_t)A | (uintptr_t)B) % 16 == 0) && (lda % 4 == 0) && (ldb % 4 == 0);
   // Tile and split-K choice by a cost model fitted to a sweep of the step's shapes on MI355X (microseconds).
   // A workgroup alone on a CU needs L per K slab (latency-bound); n workgroups sharing a CU overlap and finish a
@@ -483,7 +628,7 @@ extern "C" int cg_gemm(float* C, int ldc, const void* A, int lda, const void* B,
   const int nk = half ? (K + BKH - 1) / BKH : (K + BK - 1) / BK;
   const size_t per = (size_t)M * N * sizeof(float);
   struct Cand { int bm, bn; double L, S, P; };
-  static const Cand cand_f32[3] = {{128, 128, 2.45, 2.21, 6.0}, {128, 64, 1.48, 1.232, 4.0}, {64, 64, 1.0, 0.64, 2.5}};
+  static const Cand cand_f32[3] = {{128, 128, 2.275, 2.057, 8.26}, {128, 64, 0.733, 1.081, 7.08}, {64, 64, 0.591, 0.564, 5.61}};
   static const Cand cand_bf16[3] = {{128, 128, 1.2, 0.65, 6.0}, {128, 64, 0.8, 0.45, 4.0}, {64, 64, 0.9, 0.25, 2.5}};
   const Cand* cands = half ? cand_bf16 : cand_f32;
   static const int split_choices[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
@@ -499,7 +644,7 @@ extern "C" int cg_gemm(float* C, int ldc, const void* A, int lda, const void* B,
       const long n = (blocks + 255) / 256;
       const int slabs = (nk + sp - 1) / sp;
       double cost = slabs * (n * cands[c].S > cands[c].L ? n * cands[c].S : cands[c].L) + cands[c].P * (accumulate ? 1.5 : 1.0);
-      if (sp > 1) cost += 6.0 + (sp + 1) * (double)per / 4.0e6;
+      if (sp > 1) cost += (half ? 6.0 + (sp + 1) * (double)per / 4.0e6 : 3.36 + (sp + 1) * (double)per / 15.9e6);
       cost *= tile_bias[c];
       if (cost < best_cost) { best_cost = cost; best = c; best_splits = sp; }
     }

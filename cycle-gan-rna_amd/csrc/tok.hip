@@ -102,13 +102,25 @@ __device__ __forceinline__ void block_stats(double* part, const Row& a, const Ro
     part[(size_t)blockIdx.x * 32 + s] = ((red[s] + red[32 + s]) + red[64 + s]) + red[96 + s];
 }
 
-// Re-add the per-workgroup partials in workgroup order; tot: 32 doubles in LDS, valid after the call.
-__device__ __forceinline__ void total_stats(double* tot, const double* part, int nblk) {
-  if (threadIdx.x < 32) {
-    double a = 0.0;
-    for (int b = 0; b < nblk; ++b) a += part[(size_t)b * 32 + threadIdx.x];
-    tot[threadIdx.x] = a;
+// Re-add the per-workgroup partials; tot: 32 doubles in LDS, valid after the call.  Each quarter of the workgroup
+// adds a contiguous quarter of the partials in workgroup order (eight loads in flight at a time: the loads, not the
+// additions, are what takes time), then the four sums are added in quarter order: a fixed order, the same bits on
+// every run.  red4: 4*32 doubles of LDS that nothing else is using at this point.
+__device__ __forceinline__ void total_stats(double* tot, const double* part, int nblk, double* red4) {
+  const int s = threadIdx.x & 31, q = threadIdx.x >> 5;
+  const int per = (nblk + 3) >> 2;
+  const int b0 = q * per, b1 = min(nblk, b0 + per);
+  double a = 0.0;
+  for (int b = b0; b < b1; b += 8) {
+    double v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = b + k < b1 ? part[(size_t)(b + k) * 32 + s] : 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a += v[k];
   }
+  red4[q * 32 + s] = a;
+  __syncthreads();
+  if (threadIdx.x < 32) tot[s] = ((red4[s] + red4[32 + s]) + red4[64 + s]) + red4[96 + s];
   __syncthreads();
 }
 
@@ -196,7 +208,7 @@ __global__ void __launch_bounds__(TB) tok_bn_lin_fwd(float* R, float* T2, double
   stage_weights(wl, bl, W2, b2);
   Row t1, r, t2;
   load_row(t1, T1, tok, ok);
-  total_stats(tot, stat_in, nblk);
+  total_stats(tot, stat_in, nblk, red);
   bn_fwd_cols(bc, tot, n_tok, eps, mean_out, invstd_out, rmean, rvar, momentum);
 #pragma unroll
   for (int c = 0; c < TD; ++c) {
@@ -218,13 +230,13 @@ __global__ void __launch_bounds__(TB) tok_bn_res_fwd(float* Y, const float* T2, 
                                                      const float* gamma, const float* beta, float eps,
                                                      float* mean_out, float* invstd_out, float* rmean, float* rvar,
                                                      float momentum, const float* X, int n_tok) {
-  __shared__ double tot[32];
+  __shared__ double red[4 * 32], tot[32];
   __shared__ BnCols bc;
   TOK_COMMON
   Row t2, x, y;
   load_row(t2, T2, tok, ok);
   load_row(x, X, tok, ok);
-  total_stats(tot, stat_in, nblk);
+  total_stats(tot, stat_in, nblk, red);
   bn_fwd_cols(bc, tot, n_tok, eps, mean_out, invstd_out, rmean, rvar, momentum);
 #pragma unroll
   for (int c = 0; c < TD; ++c) {
@@ -278,7 +290,7 @@ __global__ void __launch_bounds__(TB) tok_bwd_mid(float* G1, double* stat_out, f
   load_row(t2, T2, tok, ok);
   load_row(r, R, tok, ok);
   load_row(t1, T1, tok, ok);
-  total_stats(tot, stat_in, nblk);
+  total_stats(tot, stat_in, nblk, red);
 #pragma unroll
   for (int c = 0; c < TD; ++c) xh.v[c] = (t2.v[c] - mean2[c]) * invstd2[c];
   bn_bwd_row(dt2, g, xh, tot, n_tok, invstd2, gamma2, dgamma2, dbeta2);
@@ -301,7 +313,7 @@ __global__ void __launch_bounds__(TB) tok_bwd_in(float* dX, float* wpart, float*
                                                  const double* stat_in, const float* mean1, const float* invstd1,
                                                  const float* gamma1, const float* W1, int n_tok) {
   __shared__ float wl[TD * TD], tile[2 * TB * LS];
-  __shared__ double tot[32];
+  __shared__ double red[4 * 32], tot[32];
   TOK_COMMON
   stage_weights(wl, nullptr, W1, nullptr);
   Row g1, t1, xh, x, dy, dt1, dxr;
@@ -309,7 +321,7 @@ __global__ void __launch_bounds__(TB) tok_bwd_in(float* dX, float* wpart, float*
   load_row(t1, T1, tok, ok);
   load_row(x, X, tok, ok);
   load_row(dy, dY, tok, ok);
-  total_stats(tot, stat_in, nblk);
+  total_stats(tot, stat_in, nblk, red);
 #pragma unroll
   for (int c = 0; c < TD; ++c) xh.v[c] = (t1.v[c] - mean1[c]) * invstd1[c];
   bn_bwd_row(dt1, g1, xh, tot, n_tok, invstd1, gamma1, dgamma1, dbeta1);

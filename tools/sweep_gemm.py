@@ -17,14 +17,28 @@ SHAPES = [  # name, M, N, K, transA, transB, accumulate
 ]
 
 
+_STREAM = None
+
+
 def timeit(ops, C, A, B, ta, tb, acc, n=20):
-    for _ in range(3):
-        ops.gemm(C, A, B, bool(ta), bool(tb), accumulate=bool(acc))
+    """Microseconds per launch with the launches replayed from a HIP graph (no host time between kernels)."""
+    global _STREAM
+    if _STREAM is None:
+        _STREAM = torch.cuda.Stream()
+        ops.prepare_stream(_STREAM)
+    with torch.cuda.stream(_STREAM):
+        for _ in range(2):
+            ops.gemm(C, A, B, bool(ta), bool(tb), accumulate=bool(acc))
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=_STREAM):
+        for _ in range(n):
+            ops.gemm(C, A, B, bool(ta), bool(tb), accumulate=bool(acc))
+    g.replay()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(n):
-        ops.gemm(C, A, B, bool(ta), bool(tb), accumulate=bool(acc))
+    g.replay()
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / n
@@ -43,7 +57,7 @@ def main():
         for t in range(3):
             for sp in (1, 2, 3, 4, 6, 8, 12, 16):
                 os.environ["CGRNA_GEMM_FORCE"] = f"{t},{sp}"
-                res.append((timeit(ops, C, A, B, ta, tb, acc, n=10), t, sp))
+                res.append((timeit(ops, C, A, B, ta, tb, acc, n=20), t, sp))
         with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "sweep_all.csv"), "a") as f:
             for us, t, sp in res:
                 f.write(f"{name},{M},{N},{K},{ta},{tb},{acc},{t},{sp},{us:.2f}\n")
