@@ -89,6 +89,8 @@ def main():
                     help="f32: exact float32 MFMA everywhere; bf16: large dense-layer products on the bf16 MFMA")
     ap.add_argument("--no-bf16-line", action="store_true", help="skip the secondary bf16-MFMA measurement of an f32 run")
     ap.add_argument("--sequential", action="store_true", help="one stream instead of two")
+    ap.add_argument("--no-lookahead", action="store_true",
+                    help="do not issue the generators' forward passes ahead of the previous critic work")
     ap.add_argument("--gemm-shapes", action="store_true", help="print the per-shape GEMM time table to stderr")
     ap.add_argument("--only", choices=["d", "g"], help="diagnostic: time only critic steps or only generator steps")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying HIP graphs")
@@ -124,9 +126,20 @@ def main():
     if not a.eager:
         eng.enable_graphs()
 
+    lookahead = not (a.sequential or a.only or a.no_lookahead or world > 1)
+    if lookahead:
+        eng.enable_lookahead()
+
+    def batch(i):
+        s = (i % 16) * B
+        return xm[s:s + B], xh[s:s + B], lm[s:s + B], lh[s:s + B]
+
     def step(i):
         s = (i % 16) * B
         noise.begin_step()
+        if eng.lookahead:      # the same iteration with the generators' forward passes issued ahead of the critics' work
+            eng.iteration(i, *batch(i), noise, nxt=batch(i + 1), metrics=False)
+            return
         if a.only != "g":
             eng.d_step(xm[s:s + B], xh[s:s + B], lm[s:s + B], lh[s:s + B], noise)
         if (i % NB_CRITIC == 0 and a.only != "d") or a.only == "g":
@@ -139,8 +152,9 @@ def main():
             torch.cuda.synchronize()
 
     if eng.use_graphs:
-        for _ in range(2):      # first call of each half runs eagerly, the second is captured; neither is timed
-            step(0)
+        # every graph runs eagerly on its first call and is captured on its second; neither is timed
+        for i in range(2 * NB_CRITIC + 2 if eng.lookahead else 2):
+            step(0 if not eng.lookahead else i)
     for i in range(a.warmup):
         step(i)
     fence()
@@ -162,6 +176,7 @@ def main():
         # and each bracketed by HIP events on the launch stream.  A block of filler work is queued first so that the
         # host runs ahead of the GPU and the event pairs time the kernels, not the gaps between launches.
         eng.use_graphs = False
+        eng.lookahead = False
         eng.concurrent = False         # one stream: every launch is timed with the chip to itself
         filler_a = torch.rand(4096, 4096, device=dev)
         filler_c = torch.empty(4096, 4096, device=dev)
@@ -213,14 +228,20 @@ def main():
         if not a.eager:
             eng16.enable_graphs()
 
+        if lookahead:
+            eng16.enable_lookahead()
+
         def step16(i):
             s = (i % 16) * B
             noise.begin_step()
+            if eng16.lookahead:
+                eng16.iteration(i, *batch(i), noise, nxt=batch(i + 1), metrics=False)
+                return
             eng16.d_step(xm[s:s + B], xh[s:s + B], lm[s:s + B], lh[s:s + B], noise)
             if i % NB_CRITIC == 0:
                 eng16.g_step(xm[s:s + B], xh[s:s + B], lm[s:s + B], lh[s:s + B], noise)
-        for i in range(2 if eng16.use_graphs else 0):
-            step16(0)
+        for i in range((2 * NB_CRITIC + 2 if eng16.lookahead else 2) if eng16.use_graphs else 0):
+            step16(i if eng16.lookahead else 0)
         for i in range(a.warmup):
             step16(i)
         fence()

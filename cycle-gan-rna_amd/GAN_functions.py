@@ -560,6 +560,9 @@ def train_enhanced_cycle_gan(g_m2h, g_h2m, d_m, d_h, mouse_adata, human_adata,
                             default_generator=True)
         if config.get('concurrent_streams', True):
             eng.enable_concurrency()
+            if config.get('lookahead', True):
+                # the generators' forward of the next critic step is issued beside the critics' work of this one
+                eng.enable_lookahead()
         if config.get('hip_graphs', True):
             eng.enable_graphs()
     metrics = {k: [] for k in ('g_loss', 'd_m_loss', 'd_h_loss', 'fake_human_var', 'fake_mouse_var', 'cycle_loss',
@@ -587,26 +590,36 @@ def train_enhanced_cycle_gan(g_m2h, g_h2m, d_m, d_h, mouse_adata, human_adata,
     for epoch in epochs:
         acc = {k: [] for k, _ in key_map}
         mouse_iter, human_iter = iter(mouse_loader), iter(human_loader)
-        for i in range(max(len(mouse_loader), len(human_loader))):                             # :298-309
-            try:
-                md, mc = next(mouse_iter)
-            except StopIteration:
-                mouse_iter = iter(mouse_loader)
-                md, mc = next(mouse_iter)
-            try:
-                hd, hc = next(human_iter)
-            except StopIteration:
-                human_iter = iter(human_loader)
-                hd, hc = next(human_iter)
-            n = min(md.size(0), hd.size(0))                                                    # :315-319
-            md, hd, mc, hc = md[:n], hd[:n], mc[:n], hc[:n]
+
+        def epoch_batches(mouse_iter=mouse_iter, human_iter=human_iter):
+            for i in range(max(len(mouse_loader), len(human_loader))):                         # :298-309
+                try:
+                    md, mc = next(mouse_iter)
+                except StopIteration:
+                    mouse_iter = iter(mouse_loader)
+                    md, mc = next(mouse_iter)
+                try:
+                    hd, hc = next(human_iter)
+                except StopIteration:
+                    human_iter = iter(human_loader)
+                    hd, hc = next(human_iter)
+                n = min(md.size(0), hd.size(0))                                                # :315-319
+                yield i, (md[:n], hd[:n], mc[:n], hc[:n])
+        # one batch is drawn ahead of the iteration that uses it (within the epoch only), so that the engine can
+        # be told the next batch; the draws of the shuffling keep their order
+        batches = epoch_batches()
+        cur = next(batches, None)
+        while cur is not None:
+            nxt = next(batches, None)
+            i, batch = cur
             if hasattr(noise, "begin_step"):
                 noise.begin_step()
-            out = eng.iteration(i, md, hd, mc, hc, noise)
+            out = eng.iteration(i, *batch, noise, nxt=None if nxt is None else nxt[1])
             if out:                                                                            # :411-419
                 last = out
                 for k, src in key_map:
                     acc[k].append(out[src])
+            cur = nxt
         if config['use_lr_decay']:                                                             # :421
             current_lr, new_lr = _lr_decay_step(config, epoch)
             if new_lr is not None:

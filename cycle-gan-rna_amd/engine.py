@@ -685,6 +685,7 @@ class EngineBase:
     use_graphs = False
     concurrent = False
     _pin = None
+    _lane_sides = None      # side streams of the lane that is issuing work (None: the main lane's self.sides)
 
     # ---- two-stream concurrency ------------------------------------------------------
     def enable_concurrency(self):
@@ -707,7 +708,8 @@ class EngineBase:
                 fn()
             return
         main = torch.cuda.current_stream(self.ops.device)
-        used = self.sides[:len(branches) - 1]
+        used = (self.sides if self._lane_sides is None else self._lane_sides)[:len(branches) - 1]
+        assert len(used) == len(branches) - 1, "this lane has too few side streams"
         for st in used:
             st.wait_stream(main)
         branches[0]()
@@ -761,6 +763,7 @@ class EngineBase:
         (noise.DeviceNoise); ragged batches stay eager.  With several ranks the collectives stay outside the
         graphs (see _run_parts)."""
         self._graphs = {}
+        self._cap_streams = {}
         self.use_graphs = True
 
     def _graphed(self, kind, body, tensors, noise):
@@ -776,9 +779,15 @@ class EngineBase:
         if st["graph"] is None:
             before = {n: dict(net.nbt) for n, net in self.nets.items()}
             g = torch.cuda.CUDAGraph()
+            # one capture stream per lane, with its scratch allocated beforehand: kernels captured on it take their
+            # scratch by stream, and graphs of different lanes are replayed side by side
+            lane = "ahead" if self._lane_sides is not None else "main"
+            if lane not in self._cap_streams:
+                self._cap_streams[lane] = torch.cuda.Stream(device=self.ops.device)
+                self.ops.prepare_stream(self._cap_streams[lane])
             # thread-local capture mode: helper threads of the process (a collective backend's progress thread, for
             # one) may keep making HIP calls while this thread captures
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            with torch.cuda.graph(g, stream=self._cap_streams[lane], capture_error_mode="thread_local"):
                 body(*st["static"], noise)
             st["graph"] = g
             st["nbt"] = {n: {k: net.nbt[k] - before[n][k] for k in net.nbt} for n, net in self.nets.items()}
@@ -958,12 +967,14 @@ class StepEngine(EngineBase):
         b = mouse.shape[0]
         self.arena_d.g.zero_()
 
+        drawn, self._d_noise = self._d_noise, None
+
         def critic_fwd(name, real, real_lab, fake, fake_lab, s0):
             ds = self.dstack[name]
             ds.load(0, b, real, real_lab)
             ds.load(1, b, fake, fake_lab)
             ds.load(2, b, None, fake_lab)
-            m1, m2, alpha = self._critic_noise(noise, b, 3, alpha_before=2)
+            m1, m2, alpha = drawn[name] if drawn else self._critic_noise(noise, b, 3, alpha_before=2)
             ops.gp_interp(ds.x_seg(2, b), real, fake, alpha)
             val, _ = ds.forward(b, m1, m2, (0, 1, 2))
             ops.reduce_sum(self.red, s0, val[:b])
@@ -978,6 +989,12 @@ class StepEngine(EngineBase):
                    lambda: self.dstack["d_h"].gp_backward(b, 2, cfg["lambda_gp"], self.red, S_DH_REAL + 2))
         self.arena_d.g.add_(self.arena_d.g2)
         ops.sum_parts(self.d_tot, self.red, self.d_slots, self.d_scales)
+
+    _d_noise = None      # masks and alpha of the critic step drawn before its critics' part is issued
+
+    def _draw_d_noise(self, noise, b):
+        """The critic step's draws in the order of _d_critics (mouse critic, then human critic)."""
+        return {name: self._critic_noise(noise, b, 3, alpha_before=2) for name in ("d_m", "d_h")}
 
     def _d_update(self):
         self._adam(self.arena_d)
@@ -1138,16 +1155,155 @@ class StepEngine(EngineBase):
                     scales=dict(adv=float(t[6]), cycle=float(t[7]), celltype=float(t[8]), fm=float(t[9]), kl=float(t[10])),
                     fake_human_var=float(v[0]), fake_mouse_var=float(v[1]))
 
-    def iteration(self, i, mouse, human, mouse_cat, human_cat, noise):
+    def iteration(self, i, mouse, human, mouse_cat, human_cat, noise, nxt=None, metrics=True):
         """One pass of the loop body :298-419; returns the metrics the reference
-        records (only on generator steps, like :411-419)."""
-        self.d_step(mouse, human, mouse_cat, human_cat, noise)
+        records (only on generator steps, like :411-419).  `nxt`: the next iteration's
+        (mouse, human, mouse_cat, human_cat), used only after enable_lookahead().  metrics=False skips the
+        device-to-host read of the losses (the host then never waits for the device)."""
+        if self.lookahead and not self.sync.enabled:
+            self._iteration_lookahead(i, mouse, human, mouse_cat, human_cat, noise, nxt)
+        else:
+            self.d_step(mouse, human, mouse_cat, human_cat, noise)
+            if i % self.cfg["nb_critic"] == 0:
+                self.g_step(mouse, human, mouse_cat, human_cat, noise)
         out = {}
-        if i % self.cfg["nb_critic"] == 0:
-            self.g_step(mouse, human, mouse_cat, human_cat, noise)
+        if metrics and i % self.cfg["nb_critic"] == 0:
             out.update(self.d_losses())
             out.update(self.g_losses())
         return out
+
+    # ---- generator forwards issued ahead of the critics' work (one rank) ---------------------------------
+    lookahead = False
+
+    def enable_lookahead(self):
+        """The generators' forward passes of a critic step need nothing from the critics, and the generators only
+        change in a generator step.  With lookahead they run on a second lane (a stream with side streams and
+        scratch of its own) beside the critics' part of the previous critic step: the forward for iteration i+1
+        while the critics work on iteration i, and the first forward of a generator step beside the critics' part
+        of its own iteration.  Calls of a generator stay in the reference's order (the lane is one queue), so the
+        running statistics see the same sequence; the values computed are those of the plain schedule given the
+        same noise.  The critic step's forwards alternate between two workspaces, because one is still being read
+        by the critics when the next is written."""
+        assert self.concurrent, "enable_concurrency() first"
+        dev = self.ops.device
+        self.ahead = torch.cuda.Stream(device=dev)
+        self.ahead_sides = [torch.cuda.Stream(device=dev)]
+        for st in [self.ahead] + self.ahead_sides:
+            self.ops.prepare_stream(st)
+        N, B = self.nets, self.max_b
+        gm, gh = self.g_mouse, self.g_human
+        self.gen_d = [{"g_m2h": GenPass(self, N["g_m2h"], gm, gh, B), "g_h2m": GenPass(self, N["g_h2m"], gh, gm, B)}
+                      for _ in range(2)]
+        self._d_states = [None, None]
+        self._dset = 0
+        self._pre = None        # (workspace set, batch) of a critic-step forward already issued
+        self.lookahead = True
+
+    class _Lane:
+        """Issue work on one stream of the lookahead lane (no further forks from it)."""
+
+        def __init__(self, eng, noise, stream):
+            self.eng, self.noise, self.stream = eng, noise, stream
+
+        def __enter__(self):
+            self.ctx = torch.cuda.stream(self.stream)
+            self.ctx.__enter__()
+            self.eng._lane_sides = ()
+            if hasattr(self.noise, "space"):
+                self.noise.space = "ahead"
+
+        def __exit__(self, *exc):
+            self.eng._lane_sides = None
+            if hasattr(self.noise, "space"):
+                self.noise.space = ""
+            return self.ctx.__exit__(*exc)
+
+    def _run_graph_or_eager(self, kind, body, tensors, noise, b):
+        if self.use_graphs and b == self.max_b:
+            self._graphed(kind, body, tensors, noise)
+        else:
+            body(*tensors, noise)
+
+    def _d_gen_set(self, s):
+        def body(mouse, human, mouse_cat, human_cat, noise):
+            out = {}
+
+            def gen(which, x, lab):
+                out[which] = self.gen_d[s][which].forward(x, lab, noise)
+            self._two(lambda: gen("g_m2h", mouse, mouse_cat), lambda: gen("g_h2m", human, human_cat))
+            self._d_states[s] = (mouse, human, mouse_cat, human_cat, noise, out["g_m2h"], out["g_h2m"])
+        return body
+
+    def _d_crit_set(self, s):
+        def body(noise):
+            self._d_state = self._d_states[s]
+            self._d_critics()
+            self._d_update()
+        return body
+
+    def _g_tail(self, noise):
+        self._g_rest()
+        self._g_backward()
+        self._g_update()
+
+    def _pair_body(self, s, mode):
+        """The critics' part of a critic step on workspace set s with a generator forward beside it on the lane:
+        mode "n" - the forward of the next critic step (into the other set), mode "g" - the first forward of this
+        iteration's generator step, followed by the rest of that step.  One body, so that it is captured as one HIP
+        graph: two graphs launched on two streams do not run side by side, the branches of one graph do."""
+        def body(*a):
+            mouse, human, mouse_cat, human_cat, noise = a
+            main = torch.cuda.current_stream(self.ops.device)
+            # the critics' noise first: draws then come in the order of the plain schedule (critic step, then the
+            # forward that follows it), so both schedules see the same numbers from one generator
+            self._d_noise = self._draw_d_noise(noise, mouse.shape[0])
+            lanes = (self.ahead, self.ahead_sides[0])      # one generator each, both forked from the main stream
+            for st in lanes:
+                st.wait_stream(main)
+            passes = self.gen_a if mode == "g" else self.gen_d[1 - s]
+            with self._Lane(self, noise, lanes[0]):
+                if mode == "g":
+                    self.arena_g.g.zero_()
+                out_h = passes["g_m2h"].forward(mouse, mouse_cat, noise)
+            with self._Lane(self, noise, lanes[1]):
+                out_m = passes["g_h2m"].forward(human, human_cat, noise)
+            if mode == "g":
+                self._g_state = (mouse, human, mouse_cat, human_cat, dict(fh=out_h, fm=out_m), noise)
+            else:
+                self._d_states[1 - s] = (mouse, human, mouse_cat, human_cat, noise, out_h, out_m)
+            self._d_crit_set(s)(noise)
+            for st in lanes:
+                main.wait_stream(st)
+            if mode == "g":
+                self._g_tail(noise)
+        return body
+
+    def _iteration_lookahead(self, i, mouse, human, mouse_cat, human_cat, noise, nxt):
+        b = mouse.shape[0]
+        assert human.shape[0] == b and b <= self.max_b
+        if self._d_scales_b != b:
+            lam = float(self.cfg["lambda_gp"])
+            self.d_scales.copy_(torch.tensor([-1.0 / b, 1.0 / b, lam / b] * 2, dtype=torch.float64))
+            self._d_scales_b = b
+        ins = (mouse, human, mouse_cat, human_cat)
+        key = lambda ts: tuple((t.data_ptr(), tuple(t.shape)) for t in ts)  # noqa: E731
+        do_g = i % self.cfg["nb_critic"] == 0
+        if self._pre is not None and self._pre[1] == key(ins):
+            s = self._pre[0]
+        else:                   # nothing (or some other batch) was issued ahead: forward now
+            s = self._dset = 1 - self._dset
+            self._run_graph_or_eager(f"dgen{s}", self._d_gen_set(s), ins, noise, b)
+        self._pre = None
+        self._begin_opt(self.arena_d, self.lr_d)
+        if do_g:
+            self._begin_opt(self.arena_g, self.lr_g)
+            self._run_graph_or_eager(f"pair{s}g", self._pair_body(s, "g"), ins, noise, b)
+        elif nxt is not None and nxt[0].shape[0] == b:
+            self._dset = 1 - s
+            self._run_graph_or_eager(f"pair{s}n", self._pair_body(s, "n"), tuple(nxt), noise, b)
+            self._pre = (1 - s, key(nxt))
+        else:
+            self._run_graph_or_eager(f"dcrit{s}", self._d_crit_set(s), (), noise, b)
 
     def state_dict(self, name):
         self.flush()

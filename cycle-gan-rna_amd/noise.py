@@ -73,12 +73,13 @@ class DeviceNoise:
             self.gen.manual_seed(seed)
         self.bufs = {}
         self.count = {}
+        self.space = ""      # buffer namespace: work issued on another lane draws into buffers of its own
 
     def begin_step(self):
         self.count = {}
 
     def _buf(self, kind, shape):
-        key = (kind, tuple(shape))
+        key = (self.space, kind, tuple(shape))
         i = self.count.get(key, 0)
         self.count[key] = i + 1
         lst = self.bufs.setdefault(key, [])

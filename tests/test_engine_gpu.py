@@ -187,3 +187,96 @@ def test_bf16_mfma_path_within_stated_tolerance():
             assert rel(got[i][k], exp[i][k], FLOOR.get(k, 0.0)) <= 2e-2, (i, k, got[i][k], exp[i][k])
         d = (got[i]["fake_human"].double() - exp[i]["fake_human"].double()).abs().mean()
         assert float(d / exp[i]["fake_human"].double().abs().mean()) <= 1.5e-1, (i, float(d))
+
+
+class KeyedNoise:
+    """Noise whose values depend on what is drawn (kind, shape, how many of that kind and shape came before), not on
+    how draws of different kinds interleave: two schedules that keep the order of calls within each kind see the
+    same numbers."""
+
+    def __init__(self, device, seed):
+        self.device, self.seed, self.count = device, seed, {}
+
+    def _gen(self, kind, shape):
+        key = (kind, tuple(shape))
+        n = self.count.get(key, 0)
+        self.count[key] = n + 1
+        g = torch.Generator(device=self.device)
+        g.manual_seed(hash((self.seed, kind, tuple(shape), n)) % (2 ** 31))
+        return g
+
+    def randn(self, shape):
+        return torch.empty(shape, device=self.device).normal_(generator=self._gen("n", shape))
+
+    def keep(self, shape, p_drop):
+        return torch.empty(shape, device=self.device).bernoulli_(1.0 - p_drop, generator=self._gen("k", shape)).div_(1.0 - p_drop)
+
+    def rand(self, shape):
+        return torch.empty(shape, device=self.device).uniform_(generator=self._gen("u", shape))
+
+
+def _run_schedule(ops, nets, cfg, cm, ch, data, B, iters, lookahead, graphs, noise_fn):
+    from cycle_gan_rna_amd.engine import StepEngine
+    eng = StepEngine(nets, cfg, cm, ch, ops, B)
+    eng.enable_concurrency()
+    if lookahead:
+        eng.enable_lookahead()
+    if graphs:
+        eng.enable_graphs()
+    noise = noise_fn()
+    xm, xh, lm, lh = data
+    n = xm.shape[0] // B
+    batch = lambda i: tuple(t[(i % n) * B:(i % n + 1) * B] for t in (xm, xh, lm, lh))  # noqa: E731
+    outs = []
+    for i in range(iters):
+        if hasattr(noise, "begin_step"):
+            noise.begin_step()
+        outs.append(eng.iteration(i, *batch(i), noise, nxt=batch(i + 1) if i + 1 < iters else None))
+    torch.cuda.synchronize()
+    return eng.arena_d.p.clone(), eng.arena_g.p.clone(), outs, {n_: dict(net.nbt) for n_, net in eng.nets.items()}, \
+        {n_: {k: v.clone() for k, v in net.B.items()} for n_, net in eng.nets.items()}
+
+
+@pytest.mark.parametrize("nb_critic", [2, 3])
+def test_lookahead_schedule_equals_plain_schedule(ops, nb_critic):
+    """Generator forwards issued ahead on a second lane give the same parameters, losses and running statistics,
+    bit for bit, as the plain schedule (noise keyed by call, so both schedules see the same numbers)."""
+    cfg = small_cfg(preprocess_type="log_normalized", nb_critic=nb_critic)
+    B = 32
+    nets, xm, xh, lm, lh = make_problem(64, 56, 3 * B, cfg)
+    cm, ch = O.centroid_table(xm, lm, 12), O.centroid_table(xh, lh, 12)
+    data = [t.cuda() for t in (xm, xh, lm[:, None], lh[:, None])]
+    from cycle_gan_rna_amd.noise import DeviceNoise
+    runs = [_run_schedule(ops, nets, cfg, cm, ch, data, B, 8, la, False, lambda: KeyedNoise(ops.device, 5))
+            for la in (False, True)]
+    # one generator for everything: the lookahead schedule draws in the plain schedule's order
+    runs += [_run_schedule(ops, nets, cfg, cm, ch, data, B, 8, la, la,
+                           lambda: DeviceNoise(ops.device, seed=3, default_generator=True)) for la in (False, True)]
+    assert torch.equal(runs[2][0], runs[3][0]) and torch.equal(runs[2][1], runs[3][1])
+    runs = runs[:2]
+    (d0, g0, o0, n0, b0), (d1, g1, o1, n1, b1) = runs
+    assert n0 == n1
+    assert torch.equal(d0, d1) and torch.equal(g0, g1)
+    for a, b in zip(o0, o1):
+        assert a.keys() == b.keys()
+        for k in a:
+            if k != "scales":
+                assert a[k] == b[k], k
+    for net in b0:
+        for k in b0[net]:
+            assert torch.equal(b0[net][k], b1[net][k]), (net, k)
+
+
+def test_lookahead_graph_replay_equals_eager(ops):
+    cfg = small_cfg(preprocess_type="log_normalized", nb_critic=2)
+    B = 32
+    nets, xm, xh, lm, lh = make_problem(64, 64, 2 * B, cfg)
+    cm, ch = O.centroid_table(xm, lm, 12), O.centroid_table(xh, lh, 12)
+    data = [t.cuda() for t in (xm, xh, lm[:, None], lh[:, None])]
+    from cycle_gan_rna_amd.noise import DeviceNoise
+    runs = [_run_schedule(ops, nets, cfg, cm, ch, data, B, 11, True, gr,
+                          lambda: DeviceNoise(ops.device, seed=7, default_generator=True)) for gr in (False, True)]
+    (d0, g0, o0, n0, _), (d1, g1, o1, n1, _) = runs
+    assert n0 == n1
+    assert torch.equal(d0, d1) and torch.equal(g0, g1)
+    assert o0[-1]["g_loss"] == o1[-1]["g_loss"] and o0[-1]["d_m_loss"] == o1[-1]["d_m_loss"]

@@ -16,8 +16,9 @@ from scipy.optimize import minimize
 TILES = [(128, 128), (128, 64), (64, 64)]
 
 
-def predict(theta, M, N, K, acc, t, sp, bk):
+def predict(theta, M, N, K, acc, t, sp, bk, mm=0):
     L, S, P = theta[3 * t:3 * t + 3]
+    L, S = L * (1 + theta[11] * mm), S * (1 + theta[11] * mm)
     F, BW = theta[9], theta[10]
     bm, bn = TILES[t]
     tiles = -(-M // bm) * -(-N // bn)
@@ -38,22 +39,25 @@ def main():
         M, N, K, acc, t, sp, us = int(M), int(N), int(K), int(acc), int(t), int(sp), float(us)
         if sp > 1 and (-(-K // bk)) // sp < 4:
             continue
-        rows.append((name, M, N, K, acc, t, sp, us))
+        rows.append((name, M, N, K, acc, t, sp, us, int(ta) + (1 - int(tb))))
 
     def loss(theta):
-        e = [np.log(predict(theta, M, N, K, acc, t, sp, bk) / us) for _, M, N, K, acc, t, sp, us in rows]
+        e = [np.log(predict(theta, M, N, K, acc, t, sp, bk, mm) / us) for _, M, N, K, acc, t, sp, us, mm in rows]
         return float(np.mean(np.square(e)))
 
-    x0 = np.array([2.3, 2.0, 6.0, 1.2, 1.0, 4.0, 0.6, 0.52, 3.0, 5.0, 4.0])
-    best = minimize(loss, x0, method="Nelder-Mead", options=dict(maxiter=20000, xatol=1e-4, fatol=1e-7))
+    x0 = np.array([2.3, 2.0, 6.0, 1.2, 1.0, 4.0, 0.6, 0.52, 3.0, 5.0, 4.0, 0.1])
+    if bk == 64:
+        x0 = np.array([1.2, 0.65, 6.0, 0.8, 0.45, 4.0, 0.5, 0.25, 2.5, 5.0, 4.0, 0.5])
+    best = minimize(loss, x0, method="Nelder-Mead", options=dict(maxiter=40000, xatol=1e-4, fatol=1e-8))
+    best = minimize(loss, best.x, method="Nelder-Mead", options=dict(maxiter=40000, xatol=1e-4, fatol=1e-8))
     th = best.x
     print("rms log error %.3f" % np.sqrt(best.fun))
     for t, (bm, bn) in enumerate(TILES):
         print("  {%d, %d, %.3f, %.3f, %.2f}," % (bm, bn, th[3 * t], th[3 * t + 1], th[3 * t + 2]))
-    print("  split fixed %.2f us, partial-sum bandwidth %.2f MB/us" % (th[9], th[10]))
+    print("  split fixed %.2f us, partial-sum bandwidth %.2f MB/us, per m-major operand +%.0f%%" % (th[9], th[10], 100 * th[11]))
     by = defaultdict(list)
-    for name, M, N, K, acc, t, sp, us in rows:
-        by[(name, M, N, K, acc)].append((predict(th, M, N, K, acc, t, sp, bk), us, t, sp))
+    for name, M, N, K, acc, t, sp, us, mm in rows:
+        by[(name, M, N, K, acc)].append((predict(th, M, N, K, acc, t, sp, bk, mm), us, t, sp))
     tot_pick = tot_best = 0.0
     for key, lst in by.items():
         pick = min(lst)

@@ -58,7 +58,7 @@ def main():
             for sp in (1, 2, 3, 4, 6, 8, 12, 16):
                 os.environ["CGRNA_GEMM_FORCE"] = f"{t},{sp}"
                 res.append((timeit(ops, C, A, B, ta, tb, acc, n=20), t, sp))
-        with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "sweep_all.csv"), "a") as f:
+        with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "sweep_all%s.csv" % ("_bf16" if ops.precision == "bf16" else "")), "a") as f:
             for us, t, sp in res:
                 f.write(f"{name},{M},{N},{K},{ta},{tb},{acc},{t},{sp},{us:.2f}\n")
         res.sort()
