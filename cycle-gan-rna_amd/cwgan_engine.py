@@ -330,6 +330,7 @@ class CwganEngine(EngineBase):
                    lambda: cr.gp_backward(b, 2, float(cfg.get("lambda_gp", 10)), self.red, S_GP))
         self.arena_d.g.add_(self.arena_d.g2)
         self._adam(self.arena_d)
+        ops.sum_parts(self.tot, self.red, self.slots, self.scales)
 
     # ---- generator update (cell 3, "Train Generator") ------------------------------------------
     def g_step(self, b, cat, num, noise):
@@ -371,8 +372,34 @@ class CwganEngine(EngineBase):
 
     def d_loss_now(self):
         """d_loss of the critic update just issued (reads the device)."""
-        self.ops.sum_parts(self.tot, self.red, self.slots, self.scales)
         return self.losses()["d_loss"]
+
+    # ---- per-update losses kept on the device (train_gan averages them per epoch, cell 3) -----------------
+    LOG_ROWS = 4096
+
+    def begin_log(self):
+        if getattr(self, "_hist", None) is None:
+            self._hist = self.ops.zeros(self.LOG_ROWS, N_SLOTS, dtype=torch.float64)
+        self._kinds, self._done = [], []
+
+    def _flush_log(self):
+        t = self._hist[:len(self._kinds)].cpu()
+        f32 = lambda v: float(torch.tensor(float(v), dtype=torch.float32))  # noqa: E731
+        for row, kind in zip(t, self._kinds):
+            self._done.append((kind, f32(row[0] + row[1] + row[2]) if kind == "d" else f32(row[3])))
+        self._kinds = []
+
+    def log(self, kind):
+        """Record the loss of the update just issued ("d": critic, "g": generator) without waiting for it."""
+        if len(self._kinds) == self.LOG_ROWS:
+            self._flush_log()
+        self._hist[len(self._kinds)].copy_(self.tot)
+        self._kinds.append(kind)
+
+    def end_log(self):
+        """(critic losses, generator losses) recorded since begin_log(), in order."""
+        self._flush_log()
+        return [v for k, v in self._done if k == "d"], [v for k, v in self._done if k == "g"]
 
     def iteration(self, real, cat, num, noise):
         for _ in range(int(self.cfg["nb_critic"])):

@@ -123,3 +123,102 @@ def test_eval_generation_uses_running_statistics(ops):
         ref = W.generator_forward({k: v.clone() for k, v in g.items()}, z, cat, num, 10000, train=False)
     assert rel(out, ref) <= 1e-4
     assert rel(out.sum(1), torch.full((16,), 10000.0)) <= 1e-4
+
+
+def _notebook_problem(fx):
+    """Modules, loader and covariates of the golden function-level case (the notebook's train_gan on synthetic data)."""
+    from torch.utils.data import DataLoader, TensorDataset
+    from cycle_gan_rna_amd import cWGAN
+    cfg = dict(fx["cfg"])
+    x, _ = O.synthetic_expression(fx["N"], fx["x_dim"], 12, seed=fx["data_seed"])
+    gen = torch.Generator().manual_seed(fx["cat_seed"])
+    cat = torch.stack([torch.randint(0, v, (fx["N"],), generator=gen) for v in fx["vocab"]], dim=1).numpy()
+    torch.manual_seed(fx["init_seed"])
+    g = cWGAN.Generator(fx["x_dim"], fx["vocab"], 0, cfg["latent_dim"])
+    d = cWGAN.Discriminator(fx["x_dim"], fx["vocab"], 0)
+    loader = DataLoader(TensorDataset(x), batch_size=cfg["batch_size"], shuffle=True, drop_last=True)
+    return cWGAN, cfg, g, d, loader, cat, x
+
+
+def test_dropin_train_gan_against_notebook():
+    """The drop-in train_gan in parity mode (the notebook's CPU draws replayed) against the metrics the notebook's
+    own train_gan logged on the same seeds, and the weights it ended with."""
+    import numpy as np
+    fx = torch.load(GOLD, weights_only=True)["function"]
+    cWGAN, cfg, g, d, loader, cat, x = _notebook_problem(fx)
+    logged = []
+
+    class Run:
+        pass
+    if cWGAN.wandb is None:
+        import types
+        cWGAN.wandb = types.SimpleNamespace(run=Run(), log=lambda m: logged.append(dict(m)))
+        restore = True
+    else:
+        restore = False
+    saved = []
+    try:
+        torch.manual_seed(fx["train_seed"])
+        cWGAN.train_gan(g, d, loader, cat, np.zeros((fx["N"], 0)), dict(cfg, noise="host_replay", progress=False),
+                        torch.device("cuda:0"), save_fn=lambda G, D, e: saved.append(e))
+    finally:
+        if restore:
+            cWGAN.wandb = None
+    assert saved == [0, 2]                 # epoch % 20 == 0, and the last epoch
+    if logged:
+        for ep, (got, ref) in enumerate(zip(logged, fx["metrics"])):
+            for k in ("d_loss", "g_loss", "g_loss_main", "negative_penalty_weight"):
+                assert rel(got[k], ref[k], 0.5) <= (1e-4 if ep == 0 else 5e-3), (ep, k, got[k], ref[k])
+    for name, mod, ref in (("g", g, fx["final_g"]), ("d", d, fx["final_d"])):
+        sd = mod.state_dict()
+        for k, sp in ref.items():
+            if k in ("network.0.bias", "network.3.bias", "network.6.bias"):
+                continue
+            got = sd[k].detach().cpu().reshape(-1)[::sp["stride"]]
+            # Adam moves an element by at most lr per update whatever the gradient's size: after n updates two
+            # float32 runs may differ by a fraction of n * lr on elements with rounding-noise gradients
+            n_upd = len(fx["metrics"]) * (fx["N"] // cfg["batch_size"]) * (1 if name == "g" else cfg["nb_critic"])
+            ok = rel(got, sp["values"]) <= 3e-2 or float((got - sp["values"]).abs().max()) <= 0.35 * n_upd * cfg["lr"]
+            assert ok, (name, k, rel(got, sp["values"]), float((got - sp["values"]).abs().max()))
+
+
+def test_dropin_modules_forward_backward_and_penalty(ops):
+    """Generator / Discriminator / compute_gradient_penalty as differentiable torch modules on the HIP kernels,
+    against the oracle with the same (recorded) noise."""
+    from cycle_gan_rna_amd import cWGAN
+    from cycle_gan_rna_amd.noise import RecordedNoise
+    fx = torch.load(GOLD, weights_only=True)["module"]
+    torch.manual_seed(fx["init_seed"])
+    g = cWGAN.Generator(fx["x_dim"], fx["vocab"], 0, fx["z_dim"]).cuda()
+    d = cWGAN.Discriminator(fx["x_dim"], fx["vocab"], 0).cuda()
+    x, cat, z = fx["x"].cuda(), fx["cat"].cuda(), fx["z"].cuda()
+    num = torch.zeros(x.shape[0], 0).cuda()
+    fake = g(z, cat, num)
+    assert rel(fake.detach().cpu(), fx["fake"]) <= 1e-4
+    d._noise_source = RecordedNoise(list(fx["noise"]), "cuda:0")
+    real_v = d(x, cat, num)
+    fake_v = d(fake.detach(), cat, num)
+    gp = cWGAN.compute_gradient_penalty(d, x, fake.detach(), cat, num, "cuda:0")
+    assert rel(real_v.detach().cpu(), fx["real_v"]) <= 1e-4 and rel(fake_v.detach().cpu(), fx["fake_v"]) <= 1e-4
+    assert rel(float(gp.detach()), fx["gp"]) <= 1e-4
+    (-real_v.mean() + fake_v.mean() + 10 * gp).backward()
+    floor = 1e-3 * max(float(sp["values"].abs().max()) for sp in fx["d_grads"].values())
+    grads = dict(d.named_parameters())
+    for k, sp in fx["d_grads"].items():
+        assert rel(grads[k].grad.cpu().reshape(-1)[::sp["stride"]], sp["values"], floor) <= 0.5, k
+    # generator update through the critic: d(-mean D(G(z)))/d(generator parameters) against the oracle's autograd
+    d._noise_source = RecordedNoise(list(fx["noise"][:3]), "cuda:0")
+    g.zero_grad()
+    (-d(g(z, cat, num), cat, num).mean()).backward()
+    torch.manual_seed(fx["init_seed"])
+    gs = init_params.cwgan_generator_state(fx["x_dim"], fx["vocab"], 0, fx["z_dim"])
+    ds = init_params.cwgan_discriminator_state(fx["x_dim"], fx["vocab"], 0)
+    P = {k: v.clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in gs.items()}
+    of = W.generator_forward(P, fx["z"], fx["cat"], torch.zeros(x.shape[0], 0), 10000, True)
+    (-W.discriminator_forward(ds, of, fx["cat"], torch.zeros(x.shape[0], 0), O.RecordedNoise(list(fx["noise"][:3]))).mean()).backward()
+    gg = dict(g.named_parameters())
+    gfloor = 1e-3 * max(float(P[k].grad.abs().max()) for k in gg if P[k].grad is not None)
+    for k in gg:
+        if k in ("network.0.bias", "network.3.bias", "network.6.bias"):
+            continue
+        assert rel(gg[k].grad.cpu(), P[k].grad, gfloor) <= 0.5, k
