@@ -21,6 +21,8 @@ Extra config keys (all optional, defaults keep the reference's behaviour):
   'noise': 'device' (default; noise drawn in HBM) or 'host_replay' (drawn from
            torch's CPU generator with the reference's calls - parity mode)
   'progress': False silences tqdm/prints
+  'precision': 'bf16' runs the large dense-layer products of the training step on the bf16 MFMA (float32
+           accumulation); default 'fp32'
 """
 from __future__ import annotations
 
@@ -45,14 +47,15 @@ except ImportError:
 _OPS = {}
 
 
-def _ops(device):
+def _ops(device, precision="fp32"):
     from .ops import HipOps
     device = torch.device(device)
     if device.type != "cuda":
         raise RuntimeError("cycle-gan-rna_amd runs on a HIP device only (got device %r)" % (device,))
-    key = device.index if device.index is not None else torch.cuda.current_device()
+    index = device.index if device.index is not None else torch.cuda.current_device()
+    key = (index, precision)
     if key not in _OPS:
-        _OPS[key] = HipOps(torch.device("cuda", key))
+        _OPS[key] = HipOps(torch.device("cuda", index), precision=precision)
     return _OPS[key]
 
 
@@ -527,7 +530,7 @@ def train_enhanced_cycle_gan(g_m2h, g_h2m, d_m, d_h, mouse_adata, human_adata,
                              mouse_tensor, human_tensor, cat_tensor, human_umap_coords, umap_model,
                              idx_to_cell_type, config, device, pca_model=None, scaler=None):
     device = torch.device(device)
-    ops = _ops(device)
+    ops = _ops(device, config.get('precision', 'fp32'))
     modules = OrderedDict(g_m2h=g_m2h, g_h2m=g_h2m, d_m=d_m, d_h=d_h)
     n_mouse = mouse_tensor.size(0)
     cat = torch.as_tensor(np.asarray(cat_tensor), dtype=torch.long)
