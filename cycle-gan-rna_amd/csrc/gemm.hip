@@ -557,6 +557,66 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(GemmArgs g, int spli
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Products with one tiny dimension (the critic's one-column head, rank-one products): a 64x64 MFMA tile would be
+// mostly padding and a handful of workgroups would walk the whole K range alone.  Plain FMA kernels, exact float32, the same epilogues; sums in a fixed order.
+// ------------------------------------------------------------------------------------------------
+struct Strides {
+  long am, ak, bk, bn;   // op(A)(m,k) = A[m*am + k*ak], op(B)(k,n) = B[k*bk + n*bn]
+};
+
+// K <= 16: one thread per output element.
+__global__ void __launch_bounds__(256) gemm_small_k_kernel(GemmArgs g, Strides st) {
+  const size_t total = (size_t)g.M * g.N;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int m = (int)(i / g.N), n = (int)(i % g.N);
+    float h = g.bias ? g.bias[n] : 0.f;
+    for (int k = 0; k < g.K; ++k) h += g.A[m * st.am + k * st.ak] * g.B[k * st.bk + n * st.bn];
+    epilogue_store(g, m, n, h);
+  }
+}
+
+// N <= 2, op(A) with k contiguous: one wave per output row, lanes stride over k, butterfly sum over the lanes.
+__global__ void __launch_bounds__(256) gemm_small_n_kernel(GemmArgs g, Strides st) {
+  const int lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= g.M) return;
+  float acc[2] = {0.f, 0.f};
+  const float* a = g.A + (size_t)m * st.am;
+  for (int k = lane; k < g.K; k += 64) {
+    const float av = a[k * st.ak];
+    const float* b = g.B + (size_t)k * st.bk;
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+      if (n < g.N) acc[n] += av * b[n * st.bn];
+  }
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    if (n >= g.N) break;
+    float v = acc[n];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if (lane == 0) epilogue_store(g, m, n, v + (g.bias ? g.bias[n] : 0.f));
+  }
+}
+
+// Returns true when one of the kernels above took the product.
+bool launch_small(const GemmArgs& g, int transA, int transB, hipStream_t st) {
+  const Strides s{transA ? 1 : g.lda, transA ? g.lda : 1, transB ? 1 : g.ldb, transB ? g.ldb : 1};
+  if (g.K <= 16) {
+    size_t blocks = ((size_t)g.M * g.N + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(gemm_small_k_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g, s);
+    return true;
+  }
+  // a few columns: every wave reads B once per row it owns, which stays cheap while B is a few vectors (measured:
+  // the one-column head 7 us against 13 us for the tiled kernel; twelve columns 40 us against 13 us)
+  if (g.N <= 2 && !transA) {
+    hipLaunchKernelGGL(gemm_small_n_kernel, dim3((g.M + 3) / 4), dim3(256), 0, st, g, s);
+    return true;
+  }
+  return false;
+}
+
 template <int BM, int BN, bool HALF = false>
 int launch_f32(const GemmArgs& g, int transA, int transB, bool vec, hipStream_t st, int splits = 1) {
   GemmArgs a = g;
@@ -619,6 +679,7 @@ extern "C" int cg_gemm(float* C, int ldc, const void* A, int lda, const void* B,
   if (a_bytes >= OOB_OFF || b_bytes >= OOB_OFF) return CG_ERR_UNSUPPORTED;   // 32-bit buffer offsets
   GemmArgs g{(const float*)A, (const float*)B, C, bias, E, aux, M, N, K, lda, ldb, ldc, lde, ldaux,
              epi, accumulate, slope, 0, 1 << 30, (float*)workspace, (unsigned)a_bytes, (unsigned)b_bytes};
+  if (K > 0 && (K <= 16 || N <= 2) && launch_small(g, transA, transB, st)) return cg_launch_status();
   const bool vec = (((uintptr_t)A | (uintptr_t)B) % 16 == 0) && (lda % 4 == 0) && (ldb % 4 == 0);
   // Tile and split-K choice by a cost model fitted to a sweep of the step's shapes on MI355X (microseconds).
   // A workgroup alone on a CU needs L per K slab (latency-bound); n workgroups sharing a CU overlap and finish a

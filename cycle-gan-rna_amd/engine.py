@@ -518,9 +518,13 @@ class CriticStack:
         self.e, self.ops, self.net = engine, ops, net
         self.Gd, self.E, self.S, self.nx = in_dim, engine.emb_dim, nseg, nx
         Z, B, S = ops.zeros, max_b, nseg
-        self.x = Z(nx * B, in_dim)
+        # the first layer's input [x | emb] as the reference concatenates it (GAN_functions.py:184), so that the
+        # layer and its weight gradient are one product each; x and emb are column views
+        self.W = in_dim + self.E
+        self.xe = Z(nx * B, _pad4(self.W))
+        self.x = self.xe[:, :in_dim]
+        self.emb = self.xe[:, in_dim:self.W]
         self.lab = ops.to_device(torch.zeros(nx * B, 1, dtype=torch.int64))
-        self.emb = Z(nx * B, self.E)
         self.h0, self.a1, self.pm1 = Z(S * B, 1024), Z(S * B, 1024), Z(S * B, 1024)
         self.stats = (Z(S, 1024), Z(S, 1024))
         self.a2, self.pm2 = Z(S * B, 512), Z(S * B, 512)
@@ -534,7 +538,8 @@ class CriticStack:
         self.dsum = Z(B, 1024)
         self.demb = Z(nx * B, self.E)
         self.demb2 = Z(B, self.E)
-        self.ux = Z(B, in_dim)
+        self.uxe = Z(B, _pad4(self.W))          # d(penalty)/d(input gradient) in the gene columns, zeros under emb
+        self.ux = self.uxe[:, :in_dim]
         self.rowpen = Z(B)
         self.ubar, self.mbar = Z(1024), Z(1024)
         self.b, self.have_labels = 0, True
@@ -563,8 +568,7 @@ class CriticStack:
         else:
             emb.zero_()
         h0 = self.h0[:R]
-        ops.gemm(h0[off:], x, W1[:, :Gd], False, True, bias=P["model.0.bias"])
-        ops.gemm(h0[off:], emb, W1[:, Gd:], False, True, accumulate=True)
+        ops.gemm(h0[off:], self.xe[:Rx, :self.W], W1, False, True, bias=P["model.0.bias"])
         for k in range(S - nx):
             h0[k * b:(k + 1) * b].copy_(h0[off:off + b])
         ops.bn_fwd_seg(self.a1[:R], h0, S, order, P["model.1.weight"], P["model.1.bias"], self.stats[0], self.stats[1],
@@ -604,8 +608,7 @@ class CriticStack:
         ops.bn_bwd_seg(dh0, da1, self.h0[:R], None, self.pm1[:R], ns, self.stats[0], self.stats[1], P["model.1.weight"],
                        G["model.1.weight"], G["model.1.bias"], True, 0.2)
         gW1 = G["model.0.weight"]
-        ops.gemm(gW1[:, :Gd], dh0, self.x[:R], True, False, accumulate=True)
-        ops.gemm(gW1[:, Gd:], dh0, self.emb[:R], True, False, accumulate=True)
+        ops.gemm(gW1, dh0, self.xe[:R, :self.W], True, False, accumulate=True)
         if self.have_labels:
             ops.gemm(self.demb[:R], dh0, W1[:, Gd:], False, False)
             ops.embed_scatter(G["embeddings.0.weight"], self.demb[:R], self.lab[:R], True)
@@ -642,7 +645,7 @@ class CriticStack:
         ops, P, G, Gd = self.ops, self.net.P, self.net.G2, self.Gd
         sl = slice(seg * b, (seg + 1) * b)
         mean, invstd = self.stats[0][seg], self.stats[1][seg]
-        h0, pm1, pm2, pm3, x, emb = self.h0[sl], self.pm1[sl], self.pm2[sl], self.pm3[sl], self.x[sl], self.emb[sl]
+        h0, pm1, pm2, pm3, xe = self.h0[sl], self.pm1[sl], self.pm2[sl], self.pm3[sl], self.xe[sl, :self.W]
         W1, W2, W3, w4 = P["model.0.weight"], P["model.4.weight"], P["model.7.weight"], P["model.9.weight"]
         u3, u2, u1, u0 = self.g256[sl], self.g512[sl], self.g1024a[sl], self.g1024b[sl]
         ops.gemm(u3, self.ones[:b], w4, False, False, epi=EPI_MUL, E=pm3)
@@ -655,7 +658,7 @@ class CriticStack:
         ops.gp_penalty(ux, self.rowpen[:b], ux, lambda_gp)          # ux now holds V
         ops.reduce_sum(red, slot, self.rowpen[:b])
         gW1 = G["model.0.weight"]
-        ops.gemm(gW1[:, :Gd], u0, ux, True, False)
+        ops.gemm(gW1, u0, self.uxe[:b, :self.W], True, False)       # first touch: all columns (zeros under emb)
         w = self.h1024a[:b]
         ops.gemm(w, ux, W1[:, :Gd], False, True)
         vu1, vh0 = self.h1024b[:b], self.h1024a[:b]
@@ -670,8 +673,7 @@ class CriticStack:
         vu3 = self.h256[:b]
         ops.gemm(vu3, t2, W3, False, True, epi=EPI_MUL, E=pm3)
         ops.colsum(G["model.9.weight"], vu3, 1.0, False)
-        ops.gemm(gW1[:, :Gd], vh0, x, True, False, accumulate=True)
-        ops.gemm(gW1[:, Gd:], vh0, emb, True, False)
+        ops.gemm(gW1, vh0, xe, True, False, accumulate=True)
         if self.have_labels:
             ops.gemm(self.demb2[:b], vh0, W1[:, Gd:], False, False)
             ops.embed_scatter(G["embeddings.0.weight"], self.demb2[:b], self.lab[sl], False)

@@ -470,3 +470,32 @@ def test_attention_layernorm(ops, n_cells, train):
     ops.attn_bwd(dX, dp, ws, dev(dY), dev(X), dev(keep), dev(params), heads, True)
     close(dX, edX, 5e-5, "attn dX")
     close(dp, edp, 5e-5, "attn dparams")
+
+
+@pytest.mark.parametrize("M,N,K,ta,tb,epi,acc", [
+    (512, 12, 1024, 0, 0, EPI_NONE, 0), (1536, 1, 256, 0, 1, EPI_NONE, 0), (1, 256, 1024, 1, 0, EPI_NONE, 1),
+    (512, 256, 1, 0, 0, EPI_MUL, 0), (300, 7, 100, 0, 0, EPI_LEAKY, 0), (130, 1024, 12, 0, 1, EPI_NONE, 1),
+    (9, 200, 333, 1, 0, EPI_LEAKY, 0), (16, 130, 64, 0, 0, EPI_NONE, 1), (257, 16, 70, 0, 1, EPI_MUL, 0),
+    (5, 3, 2, 1, 1, EPI_NONE, 0)])
+def test_gemm_small_dimension_kernels(ops, M, N, K, ta, tb, epi, acc):
+    """Products with M, N or K <= 16 take plain-FMA kernels (the critic's head, the embedding slice of its first
+    layer, rank-one products): same results and epilogues as the tiled kernel, operands that are column slices."""
+    wide_a = rnd(*((K, M + 5) if ta else (M, K + 5)), seed=11)
+    wide_b = rnd(*((N, K + 3) if tb else (K, N + 3)), seed=12)
+    A = wide_a[:, 2:2 + (M if ta else K)]
+    B = wide_b[:, 1:1 + (K if tb else N)]
+    bias = rnd(N, seed=13) if not acc else None
+    E = (torch.rand(M, N, generator=torch.Generator().manual_seed(4)) < 0.7).float() / 0.7 if epi != EPI_NONE else None
+    c0 = rnd(M, N, seed=14)
+    exp = c0.double().clone()
+    aux = torch.empty(M, N, dtype=torch.float64)
+    cpu.gemm(exp, A.double(), B.double(), ta, tb, bias=None if bias is None else bias.double(), epi=epi,
+             E=None if E is None else E.double(), aux=aux if epi == EPI_LEAKY else None, slope=0.2, accumulate=bool(acc))
+    got, gaux = dev(c0.clone()), torch.zeros(M, N).cuda()
+    ops.gemm(got, dev(wide_a)[:, 2:2 + (M if ta else K)], dev(wide_b)[:, 1:1 + (K if tb else N)], ta, tb, bias=dev(bias),
+             epi=epi, E=dev(E), aux=gaux if epi == EPI_LEAKY else None, slope=0.2, accumulate=bool(acc))
+    close(got, exp, 2e-5, "small-dimension gemm")
+    if epi == EPI_LEAKY:
+        h = (A.double().t() if ta else A.double()) @ (B.double().t() if tb else B.double()) + bias.double()
+        ok = h.abs() > 1e-4
+        assert torch.allclose(gaux.cpu().double()[ok], aux[ok], rtol=1e-6, atol=0)
