@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include "common.h"
+#include "gemm_tuned.h"
 
 #ifndef CG_PF_SMALL
 #define CG_PF_SMALL 2
@@ -700,7 +701,7 @@ extern "C" int cg_gemm(float* C, int ldc, const void* A, int lda, const void* B,
   for (int c = 0; c < 3; ++c) {
     const long tiles = (long)((M + cands[c].bm - 1) / cands[c].bm) * ((N + cands[c].bn - 1) / cands[c].bn);
     for (int sp : split_choices) {
-      if (sp > 1 && (!workspace || (size_t)sp * per > workspace_bytes || nk / sp < 4)) break;
+      if (sp > 1 && (!workspace || (size_t)sp * per > workspace_bytes || nk / sp < 2)) break;
       const long blocks = tiles * sp;
       const long n = (blocks + 255) / 256;
       const int slabs = (nk + sp - 1) / sp;
@@ -709,6 +710,17 @@ extern "C" int cg_gemm(float* C, int ldc, const void* A, int lda, const void* B,
       cost *= tile_bias[c];
       if (cost < best_cost) { best_cost = cost; best = c; best_splits = sp; }
     }
+  }
+  if (!half && workspace) {      // shapes that were swept on the device: take the measured best
+    static const bool use_table = getenv("CGRNA_GEMM_NO_TABLE") == nullptr;
+    if (use_table)
+      for (const TunedGemm& t : tuned_f32)
+        if (t.M == M && t.N == N && t.K == K && t.ta == transA && t.tb == transB && t.acc == accumulate &&
+            (t.splits == 1 || (size_t)t.splits * per <= workspace_bytes)) {
+          best = t.tile;
+          best_splits = t.splits;
+          break;
+        }
   }
   if (const char* f = getenv("CGRNA_GEMM_FORCE")) {   // tuning aid: "tile,splits" with tile 0=128x128 1=128x64 2=64x64
     int t = 0, sp = 1;

@@ -64,7 +64,7 @@ class HipOps:
         key = torch.cuda.current_stream(self.device).cuda_stream
         ws = self._scratch.get(key)
         if ws is None:
-            ws = [torch.empty(8 << 20, dtype=torch.float32, device=self.device),      # 32 MiB split-K slabs
+            ws = [torch.empty(32 << 20, dtype=torch.float32, device=self.device),     # 128 MiB split-K slabs
                   torch.empty(1 << 20, dtype=torch.float64, device=self.device)]      # 8 MiB BatchNorm chunk sums
             self._scratch[key] = ws
         return ws

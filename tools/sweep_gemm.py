@@ -44,8 +44,25 @@ def timeit(ops, C, A, B, ta, tb, acc, n=20):
     return e0.elapsed_time(e1) * 1e3 / n
 
 
+def shapes_from_table(path):
+    """Shapes printed by `bench.py --gemm-shapes` (M N K tA tB acc dt | ...)."""
+    out = []
+    for line in open(path):
+        f = line.replace("|", " ").split()
+        if len(f) >= 7 and f[0].isdigit():
+            M, N, K, ta, tb, acc = (int(v) for v in f[:6])
+            if min(M, N) > 2 and K > 16:
+                out.append((f"{M}x{N}x{K}", M, N, K, ta, tb, acc))
+    return out
+
+
 def main():
-    ops = HipOps("cuda:0", precision=sys.argv[1] if len(sys.argv) > 1 else "fp32")
+    global SHAPES
+    args = [a for a in sys.argv[1:] if not a.startswith("--shapes=")]
+    for a in sys.argv[1:]:
+        if a.startswith("--shapes="):
+            SHAPES = shapes_from_table(a.split("=", 1)[1])
+    ops = HipOps("cuda:0", precision=args[0] if args else "fp32")
     g = torch.Generator(device="cuda").manual_seed(0)
     for name, M, N, K, ta, tb, acc in SHAPES:
         A = torch.rand((K, M) if ta else (M, K), device="cuda", generator=g) * 2 - 1
