@@ -225,6 +225,134 @@ __global__ void __launch_bounds__(256) bn_bwd_apply(const double* ws, float* dX,
   }
 }
 
+// ---------------- one-launch forms for a single segment of a few hundred rows ----------------
+// The two-launch forms above spread any shape over hundreds of workgroups; for the dense layers at batch 512 the
+// matrix is a few MB and the two launches (plus the gap between them) cost more than the data movement.  Here a
+// workgroup owns a strip of CWF columns over ALL rows, keeps its rows in registers (NR per thread, all loads issued
+// before the first use), reduces the column sums through LDS in row-lane order and applies them: one launch, one read.
+template <int CWF, int NS>
+__device__ __forceinline__ void strip_reduce_f(double (&s)[NS], double* lds /* NS*(256/CWF)*CWF */) {
+  constexpr int LANES = 256 / CWF;
+  const int c = threadIdx.x % CWF, r = threadIdx.x / CWF;
+#pragma unroll
+  for (int i = 0; i < NS; ++i) lds[(i * LANES + r) * CWF + c] = s[i];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    double a = 0.0;
+#pragma unroll
+    for (int rr = 0; rr < LANES; ++rr) a += lds[(i * LANES + rr) * CWF + c];
+    s[i] = a;
+  }
+}
+
+template <int CWF, int NR>
+__global__ void __launch_bounds__(256) bn_fwd_fused(float* Y, int ldy, const float* X, int ldx, int M, int N,
+                                                    const float* gamma, const float* beta, float eps, float* mean_out,
+                                                    float* invstd_out, float* rmean, float* rvar, float momentum,
+                                                    float slope, const float* mask, int ldmask, float* pm_out, int ldpm,
+                                                    u16* ybf, int ldybf) {
+  constexpr int LANES = 256 / CWF;
+  __shared__ double lds[2 * 256];
+  const int c = threadIdx.x % CWF, r0 = threadIdx.x / CWF, col = blockIdx.x * CWF + c;
+  const bool ok = col < N;
+  // every load is unconditional (row and column clamped into the matrix, the value discarded afterwards): a branch
+  // around a load makes the compiler wait for each load before issuing the next
+  const int colc = min(col, N - 1);
+  float x[NR];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) x[i] = X[(size_t)min(r0 + i * LANES, M - 1) * ldx + colc];
+  double s[2] = {0.0, 0.0};
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const double xd = (r0 + i * LANES < M) ? x[i] : 0.f;
+    s[0] += xd;
+    s[1] += xd * xd;
+  }
+  strip_reduce_f<CWF, 2>(s, lds);
+  if (!ok) return;
+  const double mean_d = s[0] / M;
+  double var_d = s[1] / M - mean_d * mean_d;
+  if (var_d < 0.0) var_d = 0.0;
+  const float mean = (float)mean_d, invstd = (float)(1.0 / sqrt(var_d + (double)eps));
+  if (r0 == 0) {
+    mean_out[col] = mean;
+    invstd_out[col] = invstd;
+    if (rmean) rmean[col] = (1.f - momentum) * rmean[col] + momentum * mean;
+    if (rvar) {
+      const float unb = (float)(var_d * ((double)M / (double)(M > 1 ? M - 1 : 1)));
+      rvar[col] = (1.f - momentum) * rvar[col] + momentum * unb;
+    }
+  }
+  const float ga = gamma[col], be = beta[col];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const int m = r0 + i * LANES;
+    if (m >= M) break;
+    const float h = (x[i] - mean) * invstd * ga + be;
+    float pm = h > 0.f ? 1.f : slope;
+    if (mask) pm *= mask[(size_t)m * ldmask + col];
+    const float y = h * pm;
+    Y[(size_t)m * ldy + col] = y;
+    if (pm_out) pm_out[(size_t)m * ldpm + col] = pm;
+    if (ybf) ybf[(size_t)m * ldybf + col] = f2bf(y);
+  }
+}
+
+template <int CWF, int NR>
+__global__ void __launch_bounds__(256) bn_bwd_fused(float* dX, int lddx, const float* dY, int lddy, const float* X,
+                                                    int ldx, const float* Y, int ldy, const float* PM, int ldpm,
+                                                    const float* mean, const float* invstd, const float* gamma,
+                                                    float* dgamma, float* dbeta, int accumulate, float* gbar_out,
+                                                    float* gxbar_out, float slope, int M, int N) {
+  constexpr int LANES = 256 / CWF;
+  __shared__ double lds[2 * 256];
+  const int c = threadIdx.x % CWF, r0 = threadIdx.x / CWF, col = blockIdx.x * CWF + c;
+  const bool ok = col < N;
+  const float mu = ok ? mean[col] : 0.f, is = ok ? invstd[col] : 0.f;
+  const int colc = min(col, N - 1);       // unconditional loads, see bn_fwd_fused
+  float g[NR], xh[NR];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) g[i] = dY[(size_t)min(r0 + i * LANES, M - 1) * lddy + colc];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) xh[i] = X[(size_t)min(r0 + i * LANES, M - 1) * ldx + colc];
+  if (PM) {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) g[i] *= PM[(size_t)min(r0 + i * LANES, M - 1) * ldpm + colc];
+  } else if (Y) {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) g[i] *= Y[(size_t)min(r0 + i * LANES, M - 1) * ldy + colc] > 0.f ? 1.f : slope;
+  }
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const bool in = ok && r0 + i * LANES < M;
+    g[i] = in ? g[i] : 0.f;
+    xh[i] = in ? (xh[i] - mu) * is : 0.f;
+  }
+  double s[2] = {0.0, 0.0};
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    s[0] += g[i];
+    s[1] += (double)g[i] * xh[i];
+  }
+  strip_reduce_f<CWF, 2>(s, lds);
+  if (!ok) return;
+  const float gbar = (float)(s[0] / M), gxbar = (float)(s[1] / M);
+  if (r0 == 0) {
+    if (dbeta) dbeta[col] = (accumulate ? dbeta[col] : 0.f) + (float)s[0];
+    if (dgamma) dgamma[col] = (accumulate ? dgamma[col] : 0.f) + (float)s[1];
+    if (gbar_out) gbar_out[col] = gbar;
+    if (gxbar_out) gxbar_out[col] = gxbar;
+  }
+  const float k = is * gamma[col];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const int m = r0 + i * LANES;
+    if (m >= M) break;
+    dX[(size_t)m * lddx + col] = k * (g[i] - gbar - xh[i] * gxbar);
+  }
+}
+
 // ---------------- backward of backward ----------------
 __global__ void __launch_bounds__(256) bn_bb_stats(double* ws, const float* W, int ldw, const float* U1, int ldu,
                                                    const float* X, int ldx, const float* mean, const float* invstd,
@@ -292,6 +420,15 @@ extern "C" int cg_bn_fwd_seg(float* Y, int ldy, const float* X, int ldx, int seg
   if (seen != (1u << nseg) - 1) return CG_ERR_BAD_ARG;          // `order` must be a permutation of 0..nseg-1
   if (ldy < N || ldx < N || (mask && ldmask < N) || (pm_out && ldpm < N) || (ybf16 && ldybf16 < N)) return CG_ERR_BAD_ARG;
   if (!workspace || workspace_bytes < nseg * cg_bn_workspace_bytes(M, N)) return CG_ERR_WORKSPACE;
+  if (nseg == 1 && M <= 512 && N >= 256) {      // one launch (see bn_fwd_fused), 32 rows per thread
+#define CG_BN_FWD_FUSED(CWF, NR)                                                                                    \
+  hipLaunchKernelGGL((bn_fwd_fused<CWF, NR>), dim3((N + CWF - 1) / CWF), dim3(256), 0, (hipStream_t)stream, Y, ldy,  \
+                     X, ldx, M, N, gamma, beta, eps, mean_out, invstd_out, running_mean, running_var, momentum,      \
+                     slope, mask, ldmask, pm_out, ldpm, (u16*)ybf16, ldybf16)
+    CG_BN_FWD_FUSED(16, 32);      // measured: 7 us at 512 x 512..2048 (strips of 32 columns, 64 rows per thread: 12 us)
+#undef CG_BN_FWD_FUSED
+    return cg_launch_status();
+  }
   const Geo g = geo(M, N);
   dim3 grid(g.strips, g.rc, nseg);
   hipLaunchKernelGGL(bn_fwd_stats, grid, dim3(256), 0, (hipStream_t)stream, (double*)workspace, X, ldx, M, N, g.rows);
@@ -340,6 +477,12 @@ extern "C" int cg_bn_bwd_seg(float* dX, int lddx, const float* dY, int lddy, con
   if (!dX || !dY || !X || !mean || !invstd || !gamma || M <= 0 || N <= 0 || nseg < 1 || nseg > 8) return CG_ERR_BAD_ARG;
   if (lddx < N || lddy < N || ldx < N || (Y && ldy < N) || (PM && ldpm < N)) return CG_ERR_BAD_ARG;
   if (!workspace || workspace_bytes < nseg * cg_bn_workspace_bytes(M, N)) return CG_ERR_WORKSPACE;
+  if (nseg == 1 && M <= 512 && N >= 256) {      // one launch (see bn_bwd_fused)
+    hipLaunchKernelGGL((bn_bwd_fused<16, 32>), dim3((N + 15) / 16), dim3(256), 0, (hipStream_t)stream, dX, lddx, dY,
+                       lddy, X, ldx, Y, ldy, PM, ldpm, mean, invstd, gamma, dgamma, dbeta, accumulate, gbar_out,
+                       gxbar_out, slope, M, N);
+    return cg_launch_status();
+  }
   const Geo g = geo(M, N);
   dim3 grid(g.strips, g.rc, nseg);
   hipLaunchKernelGGL(bn_bwd_stats, grid, dim3(256), 0, (hipStream_t)stream, (double*)workspace, dY, lddy, X, ldx, Y,

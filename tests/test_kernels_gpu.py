@@ -148,7 +148,7 @@ def test_gemm_rejects_bad_arguments(ops):
         ops.gemm(c, a, torch.zeros(4, 8).cuda(), False, True, epi=EPI_MUL)   # E missing
 
 
-@pytest.mark.parametrize("M,N,slope,use_mask", [(512, 2048, 0.0, False), (37, 100, 0.2, True), (8192, 16, 1.0, False),
+@pytest.mark.parametrize("M,N,slope,use_mask", [(512, 2048, 0.0, False), (37, 100, 0.2, True), (512, 512, 0.2, True), (300, 1000, 0.0, False), (129, 256, 1.0, True), (8192, 16, 1.0, False),
                                                 (5, 33, 0.0, False), (128, 1024, 0.2, True)])
 def test_bn_fwd_bwd(ops, M, N, slope, use_mask):
     X = rnd(M, N, seed=1) * 2 + 0.7
