@@ -56,30 +56,41 @@ __global__ void embed_gather_kernel(float* out, int ldo, const float* table, int
   out[(size_t)m * ldo + e] = table[t * E + e];
 }
 
-// One block per table row (cell type): 32 row lanes x 32 column lanes walk the batch, then the row lanes are
-// combined through LDS in a fixed order (deterministic; embedding widths up to 128).
+// One block per table row (cell type): 64 row lanes x 16 column lanes walk the batch, then the row lanes are
+// combined through LDS in a fixed order (deterministic; embedding widths up to 128).  Loads are unconditional
+// (columns clamped, rows of other types discarded) and four rows are in flight per thread.
 __global__ void __launch_bounds__(1024) embed_scatter_kernel(float* dtable, int E, const float* dout, int lddo,
                                                             const int64_t* labels, int lstride, int M, int n_types,
                                                             int accumulate) {
-  __shared__ float lds[32][128];
+  __shared__ float lds[64][128];
   const int t = blockIdx.x;
-  const int el = threadIdx.x & 31, rl = threadIdx.x >> 5;
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int m = rl; m < M; m += 32) {
-    if (labels[(size_t)m * lstride] != t) continue;
+  const int el = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int nu = (E + 15) >> 4;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int m0 = rl; m0 < M; m0 += 256) {
+    bool hit[4];
+    float v[4][8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int e = el + 32 * u;
-      if (e < E) acc[u] += dout[(size_t)m * lddo + e];
+    for (int r = 0; r < 4; ++r) {
+      const int m = min(m0 + 64 * r, M - 1);
+      hit[r] = m0 + 64 * r < M && labels[(size_t)m * lstride] == t;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (u < nu) v[r][u] = dout[(size_t)m * lddo + min(el + 16 * u, E - 1)];
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (u < nu) acc[u] += (hit[r] && el + 16 * u < E) ? v[r][u] : 0.f;
   }
 #pragma unroll
-  for (int u = 0; u < 4; ++u) lds[rl][el + 32 * u] = acc[u];
+  for (int u = 0; u < 8; ++u) lds[rl][el + 16 * u] = acc[u];
   __syncthreads();
   for (int e = threadIdx.x; e < E; e += 1024) {
     float s = 0.f;
 #pragma unroll
-    for (int r = 0; r < 32; ++r) s += lds[r][e];
+    for (int r = 0; r < 64; ++r) s += lds[r][e];
     dtable[t * E + e] = (accumulate ? dtable[t * E + e] : 0.f) + s;
   }
 }

@@ -28,15 +28,17 @@ struct Row {
   float v[TD];
 };
 
+// Token `tok` of p (zeros when !ok).  The loads are unconditional - a token past the end reads token 0 and discards
+// it - because a branch around a load makes the compiler wait for that load before it issues the next one.
 __device__ __forceinline__ void load_row(Row& r, const float* p, int tok, bool ok) {
+  const float* src = p + (size_t)(ok ? tok : 0) * TD;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    f32x4 t = {0.f, 0.f, 0.f, 0.f};
-    if (ok) t = *reinterpret_cast<const f32x4*>(p + (size_t)tok * TD + 4 * q);
-    r.v[4 * q] = t[0];
-    r.v[4 * q + 1] = t[1];
-    r.v[4 * q + 2] = t[2];
-    r.v[4 * q + 3] = t[3];
+    const f32x4 t = *reinterpret_cast<const f32x4*>(src + 4 * q);
+    r.v[4 * q] = ok ? t[0] : 0.f;
+    r.v[4 * q + 1] = ok ? t[1] : 0.f;
+    r.v[4 * q + 2] = ok ? t[2] : 0.f;
+    r.v[4 * q + 3] = ok ? t[3] : 0.f;
   }
 }
 
@@ -114,9 +116,9 @@ __device__ __forceinline__ void total_stats(double* tot, const double* part, int
   for (int b = b0; b < b1; b += 8) {
     double v[8];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = b + k < b1 ? part[(size_t)(b + k) * 32 + s] : 0.0;
+    for (int k = 0; k < 8; ++k) v[k] = part[(size_t)min(b + k, nblk - 1) * 32 + s];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) a += v[k];
+    for (int k = 0; k < 8; ++k) a += b + k < b1 ? v[k] : 0.0;
   }
   red4[q * 32 + s] = a;
   __syncthreads();
@@ -335,13 +337,26 @@ __global__ void __launch_bounds__(TB) tok_bwd_in(float* dX, float* wpart, float*
   if (ok) store_row(dX, tok, dxr);
 }
 
-__global__ void __launch_bounds__(256) tok_wgrad_reduce(float* dW2, float* dW1, const float* wpart2,
-                                                        const float* wpart1, int nblk) {
+// dW += sum of the per-workgroup partials: workgroup 0 does dW2, workgroup 1 dW1.  1024 threads: thread (q, e) adds
+// every fourth partial of element e (its loads are independent), the four sums are added in q order through LDS.
+__global__ void __launch_bounds__(1024) tok_wgrad_reduce(float* dW2, float* dW1, const float* wpart2,
+                                                         const float* wpart1, int nblk) {
+  __shared__ float part[4][TD * TD];
   float* dst = blockIdx.x == 0 ? dW2 : dW1;
   const float* src = blockIdx.x == 0 ? wpart2 : wpart1;
+  const int e = threadIdx.x & 255, q = threadIdx.x >> 8;
+  const int per = (nblk + 3) >> 2, b0 = q * per, b1 = min(nblk, b0 + per);
   float a = 0.f;
-  for (int b = 0; b < nblk; ++b) a += src[(size_t)b * (TD * TD) + threadIdx.x];
-  dst[threadIdx.x] += a;
+  for (int b = b0; b < b1; b += 8) {
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = src[(size_t)min(b + k, nblk - 1) * (TD * TD) + e];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a += b + k < b1 ? v[k] : 0.f;
+  }
+  part[q][e] = a;
+  __syncthreads();
+  if (q == 0) dst[e] += ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
 }
 
 inline bool aligned16(const void* p) { return ((uintptr_t)p % 16) == 0; }
@@ -418,6 +433,6 @@ extern "C" int cg_tok_bwd_in(float* dX, float* wpart, float* dgamma1, float* dbe
 extern "C" int cg_tok_wgrad_reduce(float* dW2, float* dW1, const float* wpart2, const float* wpart1, int n_tok,
                                    void* stream) {
   if (!dW2 || !dW1 || !wpart2 || !wpart1 || n_tok <= 0) return CG_ERR_BAD_ARG;
-  hipLaunchKernelGGL(tok_wgrad_reduce, dim3(2), dim3(256), 0, ST, dW2, dW1, wpart2, wpart1, cg_tok_blocks(n_tok));
+  hipLaunchKernelGGL(tok_wgrad_reduce, dim3(2), dim3(1024), 0, ST, dW2, dW1, wpart2, wpart1, cg_tok_blocks(n_tok));
   return cg_launch_status();
 }
