@@ -182,6 +182,16 @@ __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
   return r;
 }
 
+// LDS images: a k-major operand is [row][k] with LDH elements per row (one ds_read_b128 = the 8 consecutive k of a
+// lane's MFMA fragment).  An m-major operand stays as it lies in memory, [k][row] with ROWS + 16 elements per k row -
+// its 16-byte loads run along the rows and go to LDS untransposed, lane after lane contiguous - and the fragment is
+// fetched with two transposing reads (ds_read_b64_tr_b16: 4 k rows x 16 rows per 16-lane group, delivered
+// row-major).  Transposing in registers on the way in instead made 32 lanes of a store hit one bank.
+template <int ROWS>
+constexpr int mmaj_stride() { return ROWS + 16; }
+template <int ROWS, bool MMAJ>
+constexpr int lds_elems() { return MMAJ ? BKH * mmaj_stride<ROWS>() : ROWS * LDH; }
+
 template <int ROWS, bool MMAJ, bool VEC>
 struct StagerH {
   static constexpr int NV = ROWS * BKH / 4 / 256;   // float4 per thread (8 for 128 rows, 4 for 64)
@@ -191,59 +201,60 @@ struct StagerH {
   __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, int ld, int row0, int nrows, int k0, int K) {
     const int t = threadIdx.x;
     k0s = k0;
-    if (!MMAJ) {
 #pragma unroll
-      for (int j = 0; j < NV; ++j) {
-        const int idx = t + 256 * j;
+    for (int j = 0; j < NV; ++j) {
+      const int idx = t + 256 * j;
+      if (!MMAJ) {
         const int r = idx / (BKH / 4), kq = idx % (BKH / 4);
         const int row = row0 + r, k = k0 + 4 * kq;
         v[j] = bload4<VEC>(rs, ((unsigned)row * ld + k) * 4u, row < nrows && k < K, k, K);
-      }
-    } else {
-      // micro-tile mt = 4 k-rows x 4 rows; v[4*u + i] = k-row 4*kq+i of micro-tile u
-#pragma unroll
-      for (int u = 0; u < NV / 4; ++u) {
-        const int idx = t + 256 * u;
-        const int kq = idx / (ROWS / 4), rq = idx % (ROWS / 4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int kk = k0 + 4 * kq + i, row = row0 + 4 * rq;
-          v[4 * u + i] = bload4<VEC>(rs, ((unsigned)kk * ld + row) * 4u, kk < K && row < nrows, row, nrows);
-        }
+      } else {
+        const int k = idx / (ROWS / 4), rq = idx % (ROWS / 4);
+        const int kk = k0 + k, row = row0 + 4 * rq;
+        v[j] = bload4<VEC>(rs, ((unsigned)kk * ld + row) * 4u, kk < K && row < nrows, row, nrows);
       }
     }
   }
   __device__ __forceinline__ void store(u16* s, int row0, int nrows, int K) const {
     const int t = threadIdx.x;
-    if (!MMAJ) {
 #pragma unroll
-      for (int j = 0; j < NV; ++j) {
-        const int idx = t + 256 * j;
+    for (int j = 0; j < NV; ++j) {
+      const int idx = t + 256 * j;
+      if (!MMAJ) {
         const int r = idx / (BKH / 4), kq = idx % (BKH / 4);
         const f32x4 w = clip4<VEC>(v[j], k0s + 4 * kq, K);
         *reinterpret_cast<uint2*>(s + r * LDH + 4 * kq) = pack4(w[0], w[1], w[2], w[3]);
-      }
-    } else {
-#pragma unroll
-      for (int u = 0; u < NV / 4; ++u) {
-        const int idx = t + 256 * u;
-        const int kq = idx / (ROWS / 4), rq = idx % (ROWS / 4);
-        f32x4 w[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) w[i] = clip4<VEC>(v[4 * u + i], row0 + 4 * rq, nrows);
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-          *reinterpret_cast<uint2*>(s + (4 * rq + c) * LDH + 4 * kq) = pack4(w[0][c], w[1][c], w[2][c], w[3][c]);
+      } else {
+        const int k = idx / (ROWS / 4), rq = idx % (ROWS / 4);
+        const f32x4 w = clip4<VEC>(v[j], row0 + 4 * rq, nrows);
+        *reinterpret_cast<uint2*>(s + k * mmaj_stride<ROWS>() + 4 * rq) = pack4(w[0], w[1], w[2], w[3]);
       }
     }
   }
 };
 
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// The bf16x8 MFMA fragment of lane (lr = lane & 15, lg = lane >> 4): row `row0 + lr`, k = kbase + 8*lg + 0..7.
+template <int ROWS, bool MMAJ>
+__device__ __forceinline__ bf16x8 fragment(const u16* s, int row0, int kbase, int lr, int lg) {
+  if (!MMAJ) return *reinterpret_cast<const bf16x8*>(s + (row0 + lr) * LDH + kbase + 8 * lg);
+  // lane 4q+p of a 16-lane group names k row q, rows 4p..4p+3 of the group's block; it receives row lr, k rows 0..3
+  typedef s16x4 __attribute__((address_space(3))) * lds_s16x4;
+  const u16* p0 = s + (kbase + 8 * lg + (lr >> 2)) * mmaj_stride<ROWS>() + row0 + 4 * (lr & 3);
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(p0 + 4 * mmaj_stride<ROWS>()));
+  union { struct { s16x4 a, b; } h; bf16x8 f; } u;
+  u.h.a = lo;
+  u.h.b = hi;
+  return u.f;
+}
+
 template <int BM, int BN, bool TA, bool TB, bool VEC>
 __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgs g) {
   constexpr int TM = BM / 32, TN = BN / 32;          // 16x16 MFMA tiles per wave in each direction
   constexpr bool A_MMAJ = TA, B_MMAJ = !TB;
-  constexpr int A_ELEMS = BM * LDH, B_ELEMS = BN * LDH;
+  constexpr int A_ELEMS = lds_elems<BM, A_MMAJ>(), B_ELEMS = lds_elems<BN, B_MMAJ>();
   __shared__ __align__(16) u16 smem[2 * (A_ELEMS + B_ELEMS)];
 
   const int tile = xcd_tile();
@@ -292,10 +303,10 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgs g) {
         bf16x8 a[TM], b[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
-          a[i] = *reinterpret_cast<const bf16x8*>(As + (wm + 16 * i + lr) * LDH + 32 * ks + 8 * lg);
+          a[i] = fragment<BM, A_MMAJ>(As, wm + 16 * i, 32 * ks, lr, lg);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          b[j] = *reinterpret_cast<const bf16x8*>(Bs + (wn + 16 * j + lr) * LDH + 32 * ks + 8 * lg);
+          b[j] = fragment<BN, B_MMAJ>(Bs, wn + 16 * j, 32 * ks, lr, lg);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
