@@ -722,16 +722,19 @@ extern "C" int cg_gemm(float* C, int ldc, const void* A, int lda, const void* B,
       if (cost < best_cost) { best_cost = cost; best = c; best_splits = sp; }
     }
   }
-  if (!half && workspace) {      // shapes that were swept on the device: take the measured best
+  if (workspace) {      // shapes that were swept on the device: take the measured best
     static const bool use_table = getenv("CGRNA_GEMM_NO_TABLE") == nullptr;
-    if (use_table)
-      for (const TunedGemm& t : tuned_f32)
-        if (t.M == M && t.N == N && t.K == K && t.ta == transA && t.tb == transB && t.acc == accumulate &&
-            (t.splits == 1 || (size_t)t.splits * per <= workspace_bytes)) {
-          best = t.tile;
-          best_splits = t.splits;
-          break;
-        }
+    const TunedGemm* tab = half ? tuned_bf16 : tuned_f32;
+    const size_t ntab = half ? sizeof(tuned_bf16) / sizeof(TunedGemm) : sizeof(tuned_f32) / sizeof(TunedGemm);
+    for (size_t i = 0; use_table && i < ntab; ++i) {
+      const TunedGemm& t = tab[i];
+      if (t.M == M && t.N == N && t.K == K && t.ta == transA && t.tb == transB && t.acc == accumulate &&
+          (t.splits == 1 || (size_t)t.splits * per <= workspace_bytes)) {
+        best = t.tile;
+        best_splits = t.splits;
+        break;
+      }
+    }
   }
   if (const char* f = getenv("CGRNA_GEMM_FORCE")) {   // tuning aid: "tile,splits" with tile 0=128x128 1=128x64 2=64x64
     int t = 0, sp = 1;
