@@ -22,6 +22,16 @@
 #define CG_PF_MID 2
 #define CG_PF_BIG 2
 #endif
+#ifndef CG_PFH_SMALL
+#define CG_PFH_SMALL 2
+#define CG_PFH_MID 2
+#define CG_PFH_BIG 1
+#endif
+#ifndef CG_KWH_SMALL
+#define CG_KWH_SMALL 2
+#define CG_KWH_MID 2
+#define CG_KWH_BIG 1
+#endif
 #ifndef CG_KW_SMALL
 #define CG_KW_SMALL 2
 #define CG_KW_MID 2
@@ -52,7 +62,8 @@ constexpr int BK = 32;
 constexpr int prefetch_depth(int bm, int bn) { return bm * bn <= 64 * 64 ? CG_PF_SMALL : (bm * bn <= 128 * 64 ? CG_PF_MID : CG_PF_BIG); }
 // Wave groups per workgroup of the float32 kernel (see gemm_f32_kernel).
 constexpr int kwaves(int bm, int bn) { return bm * bn <= 64 * 64 ? CG_KW_SMALL : (bm * bn <= 128 * 64 ? CG_KW_MID : CG_KW_BIG); }
-constexpr int prefetch_depth_bf16(int bm, int bn) { return bm * bn <= 64 * 64 ? 2 : 1; }
+constexpr int prefetch_depth_bf16(int bm, int bn) { return bm * bn <= 64 * 64 ? CG_PFH_SMALL : (bm * bn <= 128 * 64 ? CG_PFH_MID : CG_PFH_BIG); }
+constexpr int kwaves_bf16(int bm, int bn) { return bm * bn <= 64 * 64 ? CG_KWH_SMALL : (bm * bn <= 128 * 64 ? CG_KWH_MID : CG_KWH_BIG); }
 
 // Operand tiles are read with buffer loads: the hardware range check returns 0 for an offset at or beyond the
 // operand's footprint, so rows and k values outside the matrix are requested at OOB_OFF and need no branch; what a
@@ -192,9 +203,10 @@ constexpr int mmaj_stride() { return ROWS + 16; }
 template <int ROWS, bool MMAJ>
 constexpr int lds_elems() { return MMAJ ? BKH * mmaj_stride<ROWS>() : ROWS * LDH; }
 
-template <int ROWS, bool MMAJ, bool VEC>
+template <int ROWS, bool MMAJ, bool VEC, int NT>
 struct StagerH {
-  static constexpr int NV = ROWS * BKH / 4 / 256;   // float4 per thread (8 for 128 rows, 4 for 64)
+  static constexpr int NV = ROWS * BKH / 4 / NT;   // float4 per thread
+  static_assert(NV >= 1 && NV * NT * 4 == ROWS * BKH, "tile does not divide over the workgroup");
   f32x4 v[NV];
   int k0s;
 
@@ -203,7 +215,7 @@ struct StagerH {
     k0s = k0;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-      const int idx = t + 256 * j;
+      const int idx = t + NT * j;
       if (!MMAJ) {
         const int r = idx / (BKH / 4), kq = idx % (BKH / 4);
         const int row = row0 + r, k = k0 + 4 * kq;
@@ -219,7 +231,7 @@ struct StagerH {
     const int t = threadIdx.x;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
-      const int idx = t + 256 * j;
+      const int idx = t + NT * j;
       if (!MMAJ) {
         const int r = idx / (BKH / 4), kq = idx % (BKH / 4);
         const f32x4 w = clip4<VEC>(v[j], k0s + 4 * kq, K);
@@ -250,8 +262,9 @@ __device__ __forceinline__ bf16x8 fragment(const u16* s, int row0, int kbase, in
   return u.f;
 }
 
-template <int BM, int BN, bool TA, bool TB, bool VEC>
-__global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgs g) {
+template <int BM, int BN, bool TA, bool TB, bool VEC, int KW>
+__global__ void __launch_bounds__(256 * KW) gemm_bf16_kernel(GemmArgs g) {
+  constexpr int NT = 256 * KW;                       // KW wave groups, each taking 1/KW of every slab (see gemm_f32_kernel)
   constexpr int TM = BM / 32, TN = BN / 32;          // 16x16 MFMA tiles per wave in each direction
   constexpr bool A_MMAJ = TA, B_MMAJ = !TB;
   constexpr int A_ELEMS = lds_elems<BM, A_MMAJ>(), B_ELEMS = lds_elems<BN, B_MMAJ>();
@@ -261,9 +274,12 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgs g) {
   int tile_m, tile_n;
   tile_coords(tile, (g.M + BM - 1) / BM, g.tiles_n, tile_m, tile_n);
   const int bm = tile_m * BM, bn = tile_n * BN;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, kg = threadIdx.x >> 8;
   const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
   const int lr = lane & 15, lg = lane >> 4;
+  constexpr int KSG = BKH / 32 / KW;                 // 32-deep MFMA steps per slab and wave group
+  static_assert(KSG * KW * 32 == BKH, "K slab does not divide over the wave groups");
+  static_assert(KW == 1 || TM * TN * 4 * 256 * (KW - 1) * 2 <= 2 * (A_ELEMS + B_ELEMS), "accumulator exchange does not fit in LDS");
 
   f32x4 acc[TM][TN];
 #pragma unroll
@@ -273,8 +289,8 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgs g) {
 
   const __amdgpu_buffer_rsrc_t rsA = make_rsrc(g.A, g.a_bytes), rsB = make_rsrc(g.B, g.b_bytes);
   constexpr int D = prefetch_depth_bf16(BM, BN);   // register stages of global loads in flight (see gemm_f32_kernel)
-  StagerH<BM, A_MMAJ, VEC> sa[D];
-  StagerH<BN, B_MMAJ, VEC> sb[D];
+  StagerH<BM, A_MMAJ, VEC, NT> sa[D];
+  StagerH<BN, B_MMAJ, VEC, NT> sb[D];
   const int nk_all = (g.K + BKH - 1) / BKH;
   const int kt0 = blockIdx.y * g.kt_per_split;
   const int nk = min(nk_all, kt0 + g.kt_per_split);
@@ -299,7 +315,8 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgs g) {
       const u16* As = smem + cur * (A_ELEMS + B_ELEMS);
       const u16* Bs = As + A_ELEMS;
 #pragma unroll
-      for (int ks = 0; ks < BKH / 32; ++ks) {
+      for (int kk = 0; kk < KSG; ++kk) {
+        const int ks = kg * KSG + kk;
         bf16x8 a[TM], b[TN];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -319,6 +336,29 @@ __global__ void __launch_bounds__(256) gemm_bf16_kernel(GemmArgs g) {
       __syncthreads();
       cur ^= 1;
     }
+  }
+
+  if (KW > 1) {   // add the wave groups' accumulators through LDS (the K loop ended on a barrier)
+    float* xs = reinterpret_cast<float*>(smem) + ((kg > 0 ? kg - 1 : 0) * 4 + wave) * (TM * TN * 4 * 64) + lane;
+    if (kg > 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) xs[((i * TN + j) * 4 + r) * 64] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (kg > 0) return;
+#pragma unroll
+    for (int q = 1; q < KW; ++q)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            acc[i][j][r] += xs[(q - 1) * 4 * (TM * TN * 4 * 64) + ((i * TN + j) * 4 + r) * 64];
   }
 
   // 16x16 accumulator: col = lane & 15, row = 4 * (lane >> 4) + reg
@@ -638,13 +678,13 @@ int launch_f32(const GemmArgs& g, int transA, int transB, bool vec, hipStream_t 
   const int nk = (g.K + bk - 1) / bk;
   a.kt_per_split = (nk + splits - 1) / splits;
   splits = (nk + a.kt_per_split - 1) / a.kt_per_split;   // no empty split
-  constexpr int KW = HALF ? 1 : kwaves(BM, BN);
+  constexpr int KW = HALF ? kwaves_bf16(BM, BN) : kwaves(BM, BN);
   dim3 grid(tm * tn, splits), block(256 * KW);
 #define CG_LAUNCH(TA, TB)                                                                    \
   do {                                                                                       \
     if (HALF) {                                                                              \
-      if (vec) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, TA, TB, true>), grid, block, 0, st, a);   \
-      else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, TA, TB, false>), grid, block, 0, st, a);      \
+      if (vec) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, TA, TB, true, KW>), grid, block, 0, st, a);   \
+      else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, TA, TB, false, KW>), grid, block, 0, st, a);      \
     } else {                                                                                 \
       if (vec) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, true, KW>), grid, block, 0, st, a);    \
       else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, false, KW>), grid, block, 0, st, a);       \
