@@ -28,6 +28,7 @@ from __future__ import annotations
 
 import json
 import os
+import weakref
 from collections import OrderedDict
 from datetime import datetime
 
@@ -213,10 +214,15 @@ class _Backend:
     module, and a forward/backward workspace."""
 
     def __init__(self, module, kind, cfg, in_dim, out_dim):
-        self.module, self.kind, self.cfg, self.in_dim, self.out_dim = module, kind, cfg, in_dim, out_dim
+        self._module = weakref.ref(module)      # the module owns this object: no cycle, no garbage-collector delay
+        self.kind, self.cfg, self.in_dim, self.out_dim = kind, cfg, in_dim, out_dim
         self.ops = None
         self.passes = {}
         self.keys = []
+
+    @property
+    def module(self):
+        return self._module()
 
     def noise(self, device):
         """Noise for one module call: a source attached by the caller as

@@ -20,6 +20,7 @@ Extra config keys (optional, defaults keep the notebook's behaviour):
 """
 from __future__ import annotations
 
+import weakref
 from collections import OrderedDict
 
 import numpy as np
@@ -46,10 +47,15 @@ class _Backend:
     it), BatchNorm buffers shared with the module, and workspaces by batch size."""
 
     def __init__(self, module, kind):
-        self.module, self.kind = module, kind
+        self._module = weakref.ref(module)      # the module owns this object: no cycle, no garbage-collector delay
+        self.kind = kind
         self.ops = None
         self.keys = []
         self.cfg = {}
+
+    @property
+    def module(self):
+        return self._module()
 
     def noise(self, device):
         src = getattr(self.module, "_noise_source", None)

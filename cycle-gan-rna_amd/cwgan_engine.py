@@ -33,7 +33,7 @@ class GenW:
 
     def __init__(self, eng, net: Net, z_dim, emb_dims, n_num, x_dim, max_b):
         ops = eng.ops
-        self.ops, self.net, self.eng = ops, net, eng
+        self.ops, self.net = ops, net
         self.z_dim, self.emb_dims, self.n_num, self.x_dim = z_dim, list(emb_dims), n_num, x_dim
         self.in_dim = z_dim + sum(emb_dims) + n_num
         Z, B = ops.zeros, max_b
@@ -108,7 +108,7 @@ class CriticW:
 
     def __init__(self, eng, net: Net, x_dim, emb_dims, n_num, max_b, nseg):
         ops = eng.ops
-        self.ops, self.net, self.eng = ops, net, eng
+        self.ops, self.net = ops, net
         self.x_dim, self.emb_dims, self.n_num, self.S = x_dim, list(emb_dims), n_num, nseg
         self.E = sum(emb_dims)
         self.in_dim = x_dim + self.E + n_num

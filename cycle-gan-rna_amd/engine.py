@@ -23,6 +23,7 @@ Adam launch updates a whole optimizer; each named parameter is a view.
 """
 from __future__ import annotations
 
+import gc
 import math
 from collections import OrderedDict
 from typing import Dict, Optional
@@ -142,7 +143,9 @@ class GenPass:
 
     def __init__(self, engine, net: Net, in_dim, out_dim, max_b):
         ops, cfg = engine.ops, engine.cfg
-        self.e, self.ops, self.net, self.cfg = engine, ops, net, cfg
+        # no reference back to the engine: an engine must die by reference count when its owner drops it, not in a
+        # later garbage-collection pass (which could run inside another engine's graph capture and destroy HIP graphs there)
+        self.ops, self.net, self.cfg = ops, net, cfg
         self.in_dim, self.out_dim = in_dim, out_dim
         self.hidden = list(cfg["hidden_dims"])
         self.L = cfg["latent_dim"]
@@ -368,7 +371,7 @@ class DiscPass:
 
     def __init__(self, engine, net: Net, in_dim, max_b):
         ops = engine.ops
-        self.e, self.ops, self.net = engine, ops, net
+        self.ops, self.net = ops, net
         self.Gd, self.E = in_dim, engine.emb_dim
         Z, B = ops.zeros, max_b
         self.emb = Z(B, self.E)
@@ -515,7 +518,7 @@ class CriticStack:
 
     def __init__(self, engine, net: Net, in_dim, max_b, nseg, nx):
         ops = engine.ops
-        self.e, self.ops, self.net = engine, ops, net
+        self.ops, self.net = ops, net
         self.Gd, self.E, self.S, self.nx = in_dim, engine.emb_dim, nseg, nx
         Z, B, S = ops.zeros, max_b, nseg
         # the first layer's input [x | emb] as the reference concatenates it (GAN_functions.py:184), so that the
@@ -789,8 +792,16 @@ class EngineBase:
                 self.ops.prepare_stream(self._cap_streams[lane])
             # thread-local capture mode: helper threads of the process (a collective backend's progress thread, for
             # one) may keep making HIP calls while this thread captures
-            with torch.cuda.graph(g, stream=self._cap_streams[lane], capture_error_mode="thread_local"):
-                body(*st["static"], noise)
+            # no garbage collection while capturing: destroying a dead object that owns HIP resources (an old graph,
+            # a stream, an event) inside a capture aborts the process
+            gc_was_on = gc.isenabled()
+            gc.disable()
+            try:
+                with torch.cuda.graph(g, stream=self._cap_streams[lane], capture_error_mode="thread_local"):
+                    body(*st["static"], noise)
+            finally:
+                if gc_was_on:
+                    gc.enable()
             st["graph"] = g
             st["nbt"] = {n: {k: net.nbt[k] - before[n][k] for k in net.nbt} for n, net in self.nets.items()}
             g.replay()
