@@ -97,23 +97,26 @@ def _attn_param_list(m):
 
 
 class _AttnFn(torch.autograd.Function):
-    """LayerNorm(x + MHA(x, x, x)) for (B, 16, 16) inputs through cg_attn_ln_fwd / cg_attn_ln_bwd."""
+    """LayerNorm(x + MHA(x, x, x)) for (B, 16, E) inputs through cg_attn_ln_fwd / cg_attn_ln_bwd."""
 
     @staticmethod
     def forward(ctx, module, x, *params):
         ops = _ops(x.device)
-        if x.shape[1:] != (16, 16) or module.num_heads != 4:
-            raise RuntimeError("the fused attention kernel handles (B, 16, 16) tokens with 4 heads")
+        e, heads = x.shape[-1], module.num_heads
+        if x.dim() != 3 or x.shape[1] != 16:
+            raise RuntimeError("the attention kernels handle (B, 16, E) token tensors (GAN_functions.py:81)")
         flat = torch.cat([p.detach().reshape(-1) for p in params]).float()
-        xc = x.detach().contiguous().float().view(-1, 16)
+        xc = x.detach().contiguous().float().view(-1, e)
+        ops.attn_bwd_ws(x.shape[0], e, heads)           # raises for a width / head count that is not built
         keep = None
         if module.training:
-            keep = torch.empty(x.shape[0] * 4, 16, 16, device=x.device).bernoulli_(0.9).div_(0.9)
+            keep = torch.empty(x.shape[0] * heads, 16, 16, device=x.device).bernoulli_(0.9).div_(0.9)
         y = torch.empty_like(xc)
-        ops.attn_fwd(y, xc, keep, flat, 4)
+        ops.attn_fwd(y, xc, keep, flat, heads)
         ctx.save_for_backward(xc, flat, keep if keep is not None else torch.empty(0, device=x.device))
         ctx.shapes = [p.shape for p in params]
         ctx.xshape = x.shape
+        ctx.heads = heads
         return y.view(x.shape)
 
     @staticmethod
@@ -121,10 +124,11 @@ class _AttnFn(torch.autograd.Function):
         xc, flat, keep = ctx.saved_tensors
         ops = _ops(dy.device)
         keep = keep if keep.numel() else None
+        e = xc.shape[1]
         dx = torch.empty_like(xc)
         dp = torch.zeros_like(flat)
-        ws = torch.empty(max(ops.attn_bwd_ws(xc.shape[0] // 16), 1), device=dy.device)
-        ops.attn_bwd(dx, dp, ws, dy.contiguous().float().view(-1, 16), xc, keep, flat, 4, False)
+        ws = torch.empty(max(ops.attn_bwd_ws(xc.shape[0] // 16, e, ctx.heads), 1), device=dy.device)
+        ops.attn_bwd(dx, dp, ws, dy.contiguous().float().view(-1, e), xc, keep, flat, ctx.heads, False)
         grads, o = [], 0
         for s in ctx.shapes:
             n = int(np.prod(s))

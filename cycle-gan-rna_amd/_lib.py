@@ -70,6 +70,7 @@ SIGNATURES = {
     "cg_adam_amsgrad": ([P, P, P, P, P, Z, P, F, F, F, P, P], I),
     "cg_attn_ln_fwd": ([P, P, P, P, I, I, I, P], I),
     "cg_attn_bwd_blocks": ([I], I),
+    "cg_attn_bwd_ws": ([I, I, I], C.c_longlong),
     "cg_attn_ln_bwd": ([P, P, P, P, P, P, P, I, I, I, I, P], I),
 }
 

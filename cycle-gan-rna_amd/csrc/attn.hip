@@ -54,6 +54,9 @@ __device__ __forceinline__ void forward_core(Fwd& f, const float* __restrict__ X
     const f32x4 t = xr[c];
     f.x[4 * c] = t[0]; f.x[4 * c + 1] = t[1]; f.x[4 * c + 2] = t[2]; f.x[4 * c + 3] = t[3];
   }
+  // this lane's own four features, fetched by address: indexing f.x with the lane's head would put the
+  // whole struct into scratch memory
+  const f32x4 xown = xr[h];
 #pragma unroll
   for (int c = 0; c < HD; ++c) {
     float q = W[OFF_BIN + 4 * h + c], k = W[OFF_BIN + 16 + 4 * h + c], v = W[OFF_BIN + 32 + 4 * h + c];
@@ -118,7 +121,7 @@ __device__ __forceinline__ void forward_core(Fwd& f, const float* __restrict__ X
     float t = W[OFF_BOUT + e];
 #pragma unroll
     for (int kk = 0; kk < E; ++kk) t += L.os[i][kk] * W[OFF_WOUT + e * E + kk];
-    f.s[c] = f.x[e] + t;
+    f.s[c] = xown[c] + t;
     m += f.s[c];
   }
   const float mean = quad_sum(m) * (1.f / E);
@@ -341,21 +344,345 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(float* __restrict__ dX, f
 
 // 32 parameters per block; 8 lanes per parameter walk the per-block partials, then a fixed-order combine.
 __global__ void __launch_bounds__(256) attn_param_reduce_kernel(float* dparams, const float* wpart, int n_blocks,
-                                                                int accumulate) {
+                                                                int accumulate, int np) {
   __shared__ float lds[8][32];
   const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
   const int t = blockIdx.x * 32 + c;
   float s = 0.f;
-  if (t < NPARAM)
-    for (int b = r; b < n_blocks; b += 8) s += wpart[(size_t)b * NPARAM + t];
+  if (t < np)
+    for (int b = r; b < n_blocks; b += 8) s += wpart[(size_t)b * np + t];
   lds[r][c] = s;
   __syncthreads();
-  if (r == 0 && t < NPARAM) {
+  if (r == 0 && t < np) {
     float a = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) a += lds[i][c];
     dparams[t] = (accumulate ? dparams[t] : 0.f) + a;
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Any other geometry: 16 tokens x EE features (EE = 4, 8, 16 or 32) and any head count that divides EE
+// (GAN_functions.py:82,:103-113 take both from the config).  One wave per workgroup, one cell at a time;
+// lane l <-> (token i = l & 15, part p = l >> 4): a lane owns EE/4 features of its token and the heads
+// p, p+4, ... .  Everything the lanes exchange goes through LDS.  Parameter block layout as above with 16 -> EE:
+//   Win[3EE][EE] | bin[3EE] | Wout[EE][EE] | bout[EE] | ln_w[EE] | ln_b[EE]
+template <int EE>
+struct Geo {
+  static constexpr int F = EE / 4;
+  static constexpr int O_WIN = 0, O_BIN = 3 * EE * EE, O_WOUT = O_BIN + 3 * EE, O_BOUT = O_WOUT + EE * EE,
+                       O_LNW = O_BOUT + EE, O_LNB = O_LNW + EE, NP = O_LNB + EE;
+  // one LDS row per token: dq | dk | dv | ds | dy*xhat | dy | x | o | 1  -- every parameter gradient is the sum
+  // over tokens of a product of two columns of this row
+  static constexpr int C_DS = 3 * EE, C_DYX = 4 * EE, C_DY = 5 * EE, C_X = 6 * EE, C_O = 7 * EE, C_ONE = 8 * EE,
+                       RS = 8 * EE + 1;
+  static constexpr int QS = 3 * EE + 1;
+  static constexpr int MAXU = (NP + 63) / 64;
+};
+
+template <int EE>
+struct GenLds {
+  float W[Geo<EE>::NP];
+  float row[S][Geo<EE>::RS];
+  float qkv[S][Geo<EE>::QS];
+  float dos[S][EE + 1];
+  float t1[4][S][S + 1];     // dscore of the 4 heads of a round, [i][j]
+  float t2[4][S][S + 1];     // p
+};
+
+// softmax row i of head h: a = probabilities, kp = keep-mask row (1 without dropout), pk = a * kp
+template <int EE>
+__device__ __forceinline__ void gen_attn_row(const GenLds<EE>& L, const float* __restrict__ keep, int cell, int H, int HD,
+                                             float scale, int h, int i, float (&a)[S], float (&kp)[S], float (&pk)[S]) {
+  const int base = h * HD;
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < S; ++j) {
+    float sc = 0.f;
+    for (int c = 0; c < HD; ++c) sc += (L.qkv[i][base + c] * scale) * L.qkv[j][EE + base + c];
+    a[j] = sc;
+    mx = fmaxf(mx, sc);
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < S; ++j) {
+    a[j] = expf(a[j] - mx);
+    sum += a[j];
+  }
+  const float inv = 1.f / sum;
+  if (keep) {
+    const f32x4* kr = reinterpret_cast<const f32x4*>(keep + (((size_t)cell * H + h) * S + i) * S);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const f32x4 t = kr[c];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) kp[4 * c + u] = t[u];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < S; ++j) kp[j] = 1.f;
+  }
+#pragma unroll
+  for (int j = 0; j < S; ++j) {
+    a[j] *= inv;
+    pk[j] = a[j] * kp[j];
+  }
+}
+
+// Forward of one cell; leaves x, o in L.row, q|k|v in L.qkv and returns this lane's normalised features.
+template <int EE>
+__device__ __forceinline__ void gen_forward(GenLds<EE>& L, const float* __restrict__ X, const float* __restrict__ keep,
+                                            int cell, int H, int HD, float scale, int lane,
+                                            float (&xhat)[Geo<EE>::F], float& rstd) {
+  using G = Geo<EE>;
+  constexpr int F = G::F;
+  const int i = lane & 15, p = lane >> 4;
+  const float* xr = X + ((size_t)cell * S + i) * EE + p * F;
+#pragma unroll
+  for (int f = 0; f < F; ++f) L.row[i][G::C_X + p * F + f] = xr[f];
+  __syncthreads();
+  for (int u = 0; u < 3 * F; ++u) {
+    const int r = p * 3 * F + u;
+    float acc = L.W[G::O_BIN + r];
+#pragma unroll
+    for (int e = 0; e < EE; ++e) acc += L.row[i][G::C_X + e] * L.W[G::O_WIN + r * EE + e];
+    L.qkv[i][r] = acc;
+  }
+  __syncthreads();
+  for (int h = p; h < H; h += 4) {
+    float a[S], kp[S], pk[S];
+    gen_attn_row<EE>(L, keep, cell, H, HD, scale, h, i, a, kp, pk);
+    const int base = h * HD;
+    for (int c = 0; c < HD; ++c) {
+      float o = 0.f;
+#pragma unroll
+      for (int j = 0; j < S; ++j) o += pk[j] * L.qkv[j][2 * EE + base + c];
+      L.row[i][G::C_O + base + c] = o;
+    }
+  }
+  __syncthreads();
+  float s[F];
+  float m = 0.f;
+#pragma unroll
+  for (int f = 0; f < F; ++f) {
+    const int e = p * F + f;
+    float t = L.W[G::O_BOUT + e];
+#pragma unroll
+    for (int k = 0; k < EE; ++k) t += L.row[i][G::C_O + k] * L.W[G::O_WOUT + e * EE + k];
+    s[f] = L.row[i][G::C_X + e] + t;
+    m += s[f];
+  }
+  const float mean = quad_sum(m) * (1.f / EE);
+  float vs = 0.f;
+#pragma unroll
+  for (int f = 0; f < F; ++f) {
+    const float d = s[f] - mean;
+    vs += d * d;
+  }
+  rstd = 1.f / sqrtf(quad_sum(vs) * (1.f / EE) + LN_EPS);
+#pragma unroll
+  for (int f = 0; f < F; ++f) xhat[f] = (s[f] - mean) * rstd;
+}
+
+template <int EE>
+__global__ void __launch_bounds__(64) attn_gen_fwd_kernel(float* __restrict__ Y, const float* __restrict__ X,
+                                                          const float* __restrict__ keep,
+                                                          const float* __restrict__ params, int n_cells, int iters,
+                                                          int H, float scale) {
+  using G = Geo<EE>;
+  __shared__ __align__(16) GenLds<EE> L;
+  for (int t = threadIdx.x; t < G::NP; t += 64) L.W[t] = params[t];
+  __syncthreads();
+  const int lane = threadIdx.x, i = lane & 15, p = lane >> 4;
+  const int HD = EE / H;
+  for (int it = 0; it < iters; ++it) {
+    const int cell_raw = it * gridDim.x + blockIdx.x;
+    const bool valid = cell_raw < n_cells;
+    const int cell = valid ? cell_raw : n_cells - 1;
+    float xhat[G::F], rstd;
+    gen_forward<EE>(L, X, keep, cell, H, HD, scale, lane, xhat, rstd);
+    if (valid) {
+      float* yr = Y + ((size_t)cell * S + i) * EE + p * G::F;
+#pragma unroll
+      for (int f = 0; f < G::F; ++f) yr[f] = xhat[f] * L.W[G::O_LNW + p * G::F + f] + L.W[G::O_LNB + p * G::F + f];
+    }
+    __syncthreads();
+  }
+}
+
+template <int EE>
+__global__ void __launch_bounds__(64) attn_gen_bwd_kernel(float* __restrict__ dX, float* __restrict__ wpart,
+                                                          const float* __restrict__ dY, const float* __restrict__ X,
+                                                          const float* __restrict__ keep,
+                                                          const float* __restrict__ params, int n_cells, int iters,
+                                                          int H, float scale) {
+  using G = Geo<EE>;
+  constexpr int F = G::F;
+  __shared__ __align__(16) GenLds<EE> L;
+  for (int t = threadIdx.x; t < G::NP; t += 64) L.W[t] = params[t];
+  const int lane = threadIdx.x, i = lane & 15, p = lane >> 4;
+  const int HD = EE / H;
+  if (p == 0) L.row[i][G::C_ONE] = 1.f;
+  // the two row columns whose product, summed over tokens, is the gradient of parameter lane + 64u
+  int colA[G::MAXU], colB[G::MAXU];
+  float acc[G::MAXU];
+#pragma unroll
+  for (int u = 0; u < G::MAXU; ++u) {
+    const int q = lane + 64 * u;
+    int a = 0, b = G::C_ONE;
+    if (q < G::O_BIN) { a = q / EE; b = G::C_X + q % EE; }
+    else if (q < G::O_WOUT) { a = q - G::O_BIN; }
+    else if (q < G::O_BOUT) { a = G::C_DS + (q - G::O_WOUT) / EE; b = G::C_O + (q - G::O_WOUT) % EE; }
+    else if (q < G::O_LNW) { a = G::C_DS + q - G::O_BOUT; }
+    else if (q < G::O_LNB) { a = G::C_DYX + q - G::O_LNW; }
+    else if (q < G::NP) { a = G::C_DY + q - G::O_LNB; }
+    colA[u] = a; colB[u] = b; acc[u] = 0.f;
+  }
+  __syncthreads();
+
+  for (int it = 0; it < iters; ++it) {
+    const int cell_raw = it * gridDim.x + blockIdx.x;
+    const bool valid = cell_raw < n_cells;
+    const int cell = valid ? cell_raw : n_cells - 1;
+    const float vscale = valid ? 1.f : 0.f;
+    float xhat[F], rstd;
+    gen_forward<EE>(L, X, keep, cell, H, HD, scale, lane, xhat, rstd);
+
+    // ---- LayerNorm backward (this lane's features of token i) ----
+    const float* dyr = dY + ((size_t)cell * S + i) * EE + p * F;
+    float ds[F], dy[F], dxh[F];
+    float m1 = 0.f, m2 = 0.f;
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+      dy[f] = dyr[f] * vscale;
+      dxh[f] = dy[f] * L.W[G::O_LNW + p * F + f];
+      m1 += dxh[f];
+      m2 += dxh[f] * xhat[f];
+    }
+    m1 = quad_sum(m1) * (1.f / EE);
+    m2 = quad_sum(m2) * (1.f / EE);
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+      const int e = p * F + f;
+      ds[f] = rstd * (dxh[f] - m1 - xhat[f] * m2);
+      L.row[i][G::C_DS + e] = ds[f];
+      L.row[i][G::C_DYX + e] = dy[f] * xhat[f];
+      L.row[i][G::C_DY + e] = dy[f];
+    }
+    __syncthreads();
+    // ---- output projection backward: do[i][k] = sum_e ds[i][e] * Wout[e][k] ----
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+      const int k = p * F + f;
+      float t = 0.f;
+#pragma unroll
+      for (int e = 0; e < EE; ++e) t += L.row[i][G::C_DS + e] * L.W[G::O_WOUT + e * EE + k];
+      L.dos[i][k] = t;
+    }
+    __syncthreads();
+    // ---- attention backward, four heads per round ----
+    for (int h0 = 0; h0 < H; h0 += 4) {
+      const int h = h0 + p;
+      const bool act = h < H;
+      const int base = h * HD;
+      if (act) {
+        float a[S], kp[S], pk[S];
+        gen_attn_row<EE>(L, keep, cell, H, HD, scale, h, i, a, kp, pk);
+        float dsc[S];
+        float tsum = 0.f;
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+          float dp = 0.f;
+          for (int c = 0; c < HD; ++c) dp += L.dos[i][base + c] * L.qkv[j][2 * EE + base + c];
+          dsc[j] = dp * kp[j];
+          tsum += dsc[j] * a[j];
+        }
+#pragma unroll
+        for (int j = 0; j < S; ++j) {
+          dsc[j] = a[j] * (dsc[j] - tsum);
+          L.t1[p][i][j] = dsc[j];
+          L.t2[p][i][j] = pk[j];
+        }
+        for (int c = 0; c < HD; ++c) {
+          float dq = 0.f;
+#pragma unroll
+          for (int j = 0; j < S; ++j) dq += dsc[j] * L.qkv[j][EE + base + c];
+          L.row[i][base + c] = dq * scale;
+        }
+      }
+      __syncthreads();
+      if (act) {      // this lane now plays key/value index j = i
+        for (int c = 0; c < HD; ++c) {
+          float dk = 0.f, dv = 0.f;
+#pragma unroll
+          for (int ii = 0; ii < S; ++ii) {
+            dk += L.t1[p][ii][i] * L.qkv[ii][base + c];
+            dv += L.t2[p][ii][i] * L.dos[ii][base + c];
+          }
+          L.row[i][EE + base + c] = dk * scale;
+          L.row[i][2 * EE + base + c] = dv;
+        }
+      }
+      __syncthreads();
+    }
+    // ---- input gradient ----
+    {
+      float* dxr = dX + ((size_t)cell * S + i) * EE + p * F;
+#pragma unroll
+      for (int f = 0; f < F; ++f) {
+        const int e = p * F + f;
+        float t = ds[f];
+        for (int r = 0; r < 3 * EE; ++r) t += L.row[i][r] * L.W[G::O_WIN + r * EE + e];
+        if (valid) dxr[f] = t;
+      }
+    }
+    // ---- parameter gradients (a cell beyond the end contributes zeros: its dy was zeroed) ----
+#pragma unroll
+    for (int u = 0; u < G::MAXU; ++u) {
+      float t = 0.f;
+#pragma unroll
+      for (int ii = 0; ii < S; ++ii) t += L.row[ii][colA[u]] * L.row[ii][colB[u]];
+      acc[u] += t;
+    }
+    __syncthreads();
+  }
+  float* outp = wpart + (size_t)blockIdx.x * G::NP;
+#pragma unroll
+  for (int u = 0; u < G::MAXU; ++u) {
+    const int q = lane + 64 * u;
+    if (q < G::NP) outp[q] = acc[u];
+  }
+}
+
+inline bool geometry_ok(int E_, int heads) {
+  return (E_ == 4 || E_ == 8 || E_ == 16 || E_ == 32) && heads >= 1 && heads <= E_ && E_ % heads == 0;
+}
+
+inline bool fused_16x4(int E_, int heads) {
+  static const bool force_generic = getenv("CGRNA_ATTN_GENERIC") != nullptr;
+  return E_ == E && heads == H && !force_generic;
+}
+
+inline int gen_blocks(int n_cells) { return n_cells < 512 ? (n_cells < 1 ? 1 : n_cells) : 512; }
+
+template <int EE>
+void launch_gen_fwd(float* Y, const float* X, const float* keep, const float* params, int n_cells, int heads,
+                    hipStream_t st) {
+  const int nb = gen_blocks(n_cells), iters = (n_cells + nb - 1) / nb;
+  const float scale = (float)sqrt(1.0 / (double)(EE / heads));
+  hipLaunchKernelGGL(attn_gen_fwd_kernel<EE>, dim3(nb), dim3(64), 0, st, Y, X, keep, params, n_cells, iters, heads,
+                     scale);
+}
+
+template <int EE>
+void launch_gen_bwd(float* dX, float* dparams, float* wpart, const float* dY, const float* X, const float* keep,
+                    const float* params, int n_cells, int heads, int accumulate, hipStream_t st) {
+  const int nb = gen_blocks(n_cells), iters = (n_cells + nb - 1) / nb;
+  const float scale = (float)sqrt(1.0 / (double)(EE / heads));
+  hipLaunchKernelGGL(attn_gen_bwd_kernel<EE>, dim3(nb), dim3(64), 0, st, dX, wpart, dY, X, keep, params, n_cells,
+                     iters, heads, scale);
+  hipLaunchKernelGGL(attn_param_reduce_kernel, dim3((Geo<EE>::NP + 31) / 32), dim3(256), 0, st, dparams, wpart, nb,
+                     accumulate, Geo<EE>::NP);
 }
 
 }  // namespace
@@ -367,15 +694,32 @@ extern "C" int cg_attn_bwd_blocks(int n_cells) {
   return nb;
 }
 
+extern "C" long long cg_attn_bwd_ws(int n_cells, int E_, int heads) {
+  if (!geometry_ok(E_, heads)) return -1;
+  if (fused_16x4(E_, heads)) return (long long)cg_attn_bwd_blocks(n_cells) * NPARAM;
+  return (long long)gen_blocks(n_cells) * (4 * E_ * E_ + 6 * E_);
+}
+
 extern "C" int cg_attn_ln_fwd(float* Y, const float* X, const float* keep, const float* params, int n_cells, int E_,
                               int heads, void* stream) {
   if (!Y || !X || !params || n_cells <= 0) return CG_ERR_BAD_ARG;
-  if (E_ != E || heads != H) return CG_ERR_UNSUPPORTED;
+  if (!geometry_ok(E_, heads)) return CG_ERR_UNSUPPORTED;
   if ((((uintptr_t)Y | (uintptr_t)X | (uintptr_t)keep) % 16) != 0) return CG_ERR_BAD_ARG;
-  int nb = (n_cells + 3) / 4;
-  if (nb > 1024) nb = 1024;
-  const int iters = (n_cells + nb * 4 - 1) / (nb * 4);
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, Y, X, keep, params, n_cells, iters);
+  hipStream_t st = (hipStream_t)stream;
+  if (fused_16x4(E_, heads)) {
+    int nb = (n_cells + 3) / 4;
+    if (nb > 1024) nb = 1024;
+    const int iters = (n_cells + nb * 4 - 1) / (nb * 4);
+    hipLaunchKernelGGL(attn_fwd_kernel, dim3(nb), dim3(256), 0, st, Y, X, keep, params, n_cells, iters);
+  } else if (E_ == 4) {
+    launch_gen_fwd<4>(Y, X, keep, params, n_cells, heads, st);
+  } else if (E_ == 8) {
+    launch_gen_fwd<8>(Y, X, keep, params, n_cells, heads, st);
+  } else if (E_ == 16) {
+    launch_gen_fwd<16>(Y, X, keep, params, n_cells, heads, st);
+  } else {
+    launch_gen_fwd<32>(Y, X, keep, params, n_cells, heads, st);
+  }
   return cg_launch_status();
 }
 
@@ -383,13 +727,23 @@ extern "C" int cg_attn_ln_bwd(float* dX, float* dparams, float* wpart, const flo
                               const float* keep, const float* params, int n_cells, int E_, int heads, int accumulate,
                               void* stream) {
   if (!dX || !dparams || !wpart || !dY || !X || !params || n_cells <= 0) return CG_ERR_BAD_ARG;
-  if (E_ != E || heads != H) return CG_ERR_UNSUPPORTED;
+  if (!geometry_ok(E_, heads)) return CG_ERR_UNSUPPORTED;
   if ((((uintptr_t)dX | (uintptr_t)dY | (uintptr_t)X | (uintptr_t)keep) % 16) != 0) return CG_ERR_BAD_ARG;
-  const int nb = cg_attn_bwd_blocks(n_cells);
-  const int iters = (n_cells + nb * 4 - 1) / (nb * 4);
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, dX, wpart, dY, X, keep, params,
-                     n_cells, iters);
-  hipLaunchKernelGGL(attn_param_reduce_kernel, dim3((NPARAM + 31) / 32), dim3(256), 0, (hipStream_t)stream, dparams,
-                     wpart, nb, accumulate);
+  hipStream_t st = (hipStream_t)stream;
+  if (fused_16x4(E_, heads)) {
+    const int nb = cg_attn_bwd_blocks(n_cells);
+    const int iters = (n_cells + nb * 4 - 1) / (nb * 4);
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3(nb), dim3(256), 0, st, dX, wpart, dY, X, keep, params, n_cells, iters);
+    hipLaunchKernelGGL(attn_param_reduce_kernel, dim3((NPARAM + 31) / 32), dim3(256), 0, st, dparams, wpart, nb,
+                       accumulate, NPARAM);
+  } else if (E_ == 4) {
+    launch_gen_bwd<4>(dX, dparams, wpart, dY, X, keep, params, n_cells, heads, accumulate, st);
+  } else if (E_ == 8) {
+    launch_gen_bwd<8>(dX, dparams, wpart, dY, X, keep, params, n_cells, heads, accumulate, st);
+  } else if (E_ == 16) {
+    launch_gen_bwd<16>(dX, dparams, wpart, dY, X, keep, params, n_cells, heads, accumulate, st);
+  } else {
+    launch_gen_bwd<32>(dX, dparams, wpart, dY, X, keep, params, n_cells, heads, accumulate, st);
+  }
   return cg_launch_status();
 }

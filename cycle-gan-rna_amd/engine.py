@@ -153,25 +153,29 @@ class GenPass:
         self.heads = cfg["num_attention_heads"]
         self.E = engine.emb_dim
         self.counts = cfg.get("preprocess_type", "counts") == "counts"
-        assert self.L // SEQ_LEN == 16 and self.heads == 4, \
-            "the fused attention kernel is built for latent_dim=256 (16 tokens x 16) and 4 heads"
-        Z, B, H, L = ops.zeros, max_b, self.hidden, self.L
+        self.D = self.L // SEQ_LEN          # token width (GAN_functions.py:82)
+        assert self.D * SEQ_LEN == self.L, "latent_dim must be divisible by seq_len"
+        # 16-wide tokens run the fused token kernels; other widths take the ResidualBlock through the GEMM and
+        # BatchNorm kernels
+        self.fused_tok = self.D == 16
+        Z, B, H, L, D = ops.zeros, max_b, self.hidden, self.L, self.D
         T = B * SEQ_LEN
         self.enc_h0 = [Z(B, h) for h in H]
         self.enc_a = [Z(B, h) for h in H]
         self.enc_stats = [(Z(h), Z(h)) for h in H]
         self.ml = Z(B, 2 * L)
         self.z = [Z(B, L) for _ in range(self.nb + 1)]
-        self.t1 = [Z(T, 16) for _ in range(self.nb)]
-        self.r = [Z(T, 16) for _ in range(self.nb)]
-        self.t2 = [Z(T, 16) for _ in range(self.nb)]
-        self.y = [Z(T, 16) for _ in range(self.nb)]
-        self.u = Z(T, 16)
-        self.rb_stats = [((Z(16), Z(16)), (Z(16), Z(16))) for _ in range(self.nb)]
+        self.t1 = [Z(T, D) for _ in range(self.nb)]
+        self.r = [Z(T, D) for _ in range(self.nb)]
+        self.t2 = [Z(T, D) for _ in range(self.nb)]
+        self.y = [Z(T, D) for _ in range(self.nb)]
+        self.u = Z(T, D)
+        self.rb_stats = [((Z(D), Z(D)), (Z(D), Z(D))) for _ in range(self.nb)]
         self.keep = [None] * self.nb
-        nblk = max(ops.tok_blocks(T), 1)
-        self.tok_stat = [Z(nblk * 32, dtype=torch.float64) for _ in range(4)]     # per-workgroup column sums
-        self.tok_wpart = [Z(nblk * 256), Z(nblk * 256)]                           # per-workgroup 16x16 weight grads
+        if self.fused_tok:
+            nblk = max(ops.tok_blocks(T), 1)
+            self.tok_stat = [Z(nblk * 32, dtype=torch.float64) for _ in range(4)]     # per-workgroup column sums
+            self.tok_wpart = [Z(nblk * 256), Z(nblk * 256)]                           # per-workgroup 16x16 weight grads
         self.dec_in = Z(B, L + self.E)
         self.dec_h0 = [Z(B, h) for h in H]
         self.dec_a = [Z(B, h) for h in H]
@@ -185,9 +189,9 @@ class GenPass:
         self.d_h0 = [Z(B, h) for h in H]
         self.d_dec_in = Z(B, L + self.E)
         self.dz = [Z(B, L), Z(B, L)]
-        self.d16 = [Z(T, 16), Z(T, 16)]
+        self.d16 = [Z(T, D), Z(T, D)]
         self.dml = Z(B, 2 * L)
-        self.attn_ws = Z(max(ops.attn_bwd_ws(B), 1))
+        self.attn_ws = Z(max(ops.attn_bwd_ws(B, D, self.heads), 1))   # raises for a geometry that is not built
         self.eps = None
         self.labels = None
         self.x = None
@@ -196,7 +200,7 @@ class GenPass:
     # attention parameter block of residual block `bi` (params or grads)
     def _attn(self, which, bi):
         first = f"residual_attention_blocks.{bi}.1.attention.in_proj_weight"
-        return self.net.arena.flat(getattr(self.net.arena, which), (self.net.name, first), 1120)
+        return self.net.arena.flat(getattr(self.net.arena, which), (self.net.name, first), 4 * self.D * self.D + 6 * self.D)
 
     def _bn(self, prefix):
         P, Bf = self.net.P, self.net.B
@@ -233,14 +237,22 @@ class GenPass:
             all_keep = noise.keep((self.nb, b * self.heads, SEQ_LEN, SEQ_LEN), 0.1)
         for bi in range(self.nb):
             pre = f"residual_attention_blocks.{bi}"
-            zin = self.z[bi][:b].view(t, 16)
+            zin = self.z[bi][:b].view(t, self.D)
             t1, r, t2, y, u = self.t1[bi][:t], self.r[bi][:t], self.t2[bi][:t], self.y[bi][:t], self.u[:t]
             (s1, s2) = self.rb_stats[bi]
             g1, b1, rm1, rv1 = self._bn(pre + ".0.block.1")
             g2, b2, rm2, rv2 = self._bn(pre + ".0.block.4")
             W1, c1 = P[pre + ".0.block.0.weight"], P[pre + ".0.block.0.bias"]
             W2, c2 = P[pre + ".0.block.3.weight"], P[pre + ".0.block.3.bias"]
-            if train:       # three fused launches: Linear | BatchNorm+ReLU+Linear | BatchNorm+residual
+            if train and not self.fused_tok:
+                ops.gemm(t1, zin, W1, False, True, bias=c1)
+                ops.bn_fwd(r, t1, g1, b1, s1[0], s1[1], rm1, rv1, 0.0)
+                ops.gemm(t2, r, W2, False, True, bias=c2)
+                ops.bn_fwd(u, t2, g2, b2, s2[0], s2[1], rm2, rv2, 1.0)
+                ops.axpby(y, 1.0, zin, 1.0, u)
+                self.net.nbt[pre + ".0.block.1.num_batches_tracked"] += 1
+                self.net.nbt[pre + ".0.block.4.num_batches_tracked"] += 1
+            elif train:     # three fused launches: Linear | BatchNorm+ReLU+Linear | BatchNorm+residual
                 sa, sb = self.tok_stat[0], self.tok_stat[1]
                 ops.tok_lin_fwd(t1, sa, zin, W1, c1)
                 ops.tok_bn_lin_fwd(r, t2, sb, t1, sa, g1, b1, s1[0], s1[1], rm1, rv1, W2, c2)
@@ -257,7 +269,7 @@ class GenPass:
                 self.keep[bi] = all_keep[bi]
             else:
                 self.keep[bi] = noise.keep((b * self.heads, SEQ_LEN, SEQ_LEN), 0.1) if train else None
-            ops.attn_fwd(self.z[bi + 1][:b].view(t, 16), y, self.keep[bi], self._attn("p", bi), self.heads)
+            ops.attn_fwd(self.z[bi + 1][:b].view(t, self.D), y, self.keep[bi], self._attn("p", bi), self.heads)
         dec_in = self.dec_in[:b]
         ops.axpby(dec_in[:, :L], 1.0, self.z[self.nb][:b])
         if labels is not None:
@@ -317,24 +329,36 @@ class GenPass:
             ops.embed_scatter(G["embeddings.0.weight"], ddi[:, L:], self.labels, True)
         cur = 0
         ops.axpby(self.dz[cur][:b], 1.0, ddi[:, :L])
-        dz = self.dz[cur][:b].view(t, 16)
+        dz = self.dz[cur][:b].view(t, self.D)
         for bi in reversed(range(self.nb)):
             pre = f"residual_attention_blocks.{bi}"
             (s1, s2) = self.rb_stats[bi]
-            dy = self.dz[1 - cur][:b].view(t, 16)
+            dy = self.dz[1 - cur][:b].view(t, self.D)
             ops.attn_bwd(dy, self._attn("g", bi), self.attn_ws, dz, self.y[bi][:t], self.keep[bi], self._attn("p", bi),
                          self.heads, True)
-            s3, s4 = self.tok_stat[2], self.tok_stat[3]
-            wp2, wp1 = self.tok_wpart
-            g1buf = self.d16[0][:t]
-            zin = self.z[bi][:b].view(t, 16)
-            ops.tok_bn_bwd_stats(s3, dy, self.t2[bi][:t], s2[0], s2[1])
-            ops.tok_bwd_mid(g1buf, s4, wp2, G[pre + ".0.block.4.weight"], G[pre + ".0.block.4.bias"], dy,
-                            self.t2[bi][:t], self.r[bi][:t], self.t1[bi][:t], s3, s2[0], s2[1],
-                            P[pre + ".0.block.4.weight"], P[pre + ".0.block.3.weight"], s1[0], s1[1])
-            ops.tok_bwd_in(dy, wp1, G[pre + ".0.block.1.weight"], G[pre + ".0.block.1.bias"], g1buf, self.t1[bi][:t],
-                           zin, dy, s4, s1[0], s1[1], P[pre + ".0.block.1.weight"], P[pre + ".0.block.0.weight"])
-            ops.tok_wgrad_reduce(G[pre + ".0.block.3.weight"], G[pre + ".0.block.0.weight"], wp2, wp1, t)
+            zin = self.z[bi][:b].view(t, self.D)
+            if self.fused_tok:
+                s3, s4 = self.tok_stat[2], self.tok_stat[3]
+                wp2, wp1 = self.tok_wpart
+                g1buf = self.d16[0][:t]
+                ops.tok_bn_bwd_stats(s3, dy, self.t2[bi][:t], s2[0], s2[1])
+                ops.tok_bwd_mid(g1buf, s4, wp2, G[pre + ".0.block.4.weight"], G[pre + ".0.block.4.bias"], dy,
+                                self.t2[bi][:t], self.r[bi][:t], self.t1[bi][:t], s3, s2[0], s2[1],
+                                P[pre + ".0.block.4.weight"], P[pre + ".0.block.3.weight"], s1[0], s1[1])
+                ops.tok_bwd_in(dy, wp1, G[pre + ".0.block.1.weight"], G[pre + ".0.block.1.bias"], g1buf,
+                               self.t1[bi][:t], zin, dy, s4, s1[0], s1[1], P[pre + ".0.block.1.weight"],
+                               P[pre + ".0.block.0.weight"])
+                ops.tok_wgrad_reduce(G[pre + ".0.block.3.weight"], G[pre + ".0.block.0.weight"], wp2, wp1, t)
+            else:           # the same chain through the general kernels; dy ends as the gradient w.r.t. zin
+                dt, dr = self.d16[0][:t], self.d16[1][:t]
+                ops.bn_bwd(dt, dy, self.t2[bi][:t], None, None, s2[0], s2[1], P[pre + ".0.block.4.weight"],
+                           G[pre + ".0.block.4.weight"], G[pre + ".0.block.4.bias"], True, 1.0)
+                ops.gemm(G[pre + ".0.block.3.weight"], dt, self.r[bi][:t], True, False, accumulate=True)
+                ops.gemm(dr, dt, P[pre + ".0.block.3.weight"], False, False)
+                ops.bn_bwd(dt, dr, self.t1[bi][:t], self.r[bi][:t], None, s1[0], s1[1], P[pre + ".0.block.1.weight"],
+                           G[pre + ".0.block.1.weight"], G[pre + ".0.block.1.bias"], True, 0.0)
+                ops.gemm(G[pre + ".0.block.0.weight"], dt, zin, True, False, accumulate=True)
+                ops.gemm(dy, dt, P[pre + ".0.block.0.weight"], False, False, accumulate=True)
             cur = 1 - cur
             dz = dy
         dz0 = self.dz[cur][:b]

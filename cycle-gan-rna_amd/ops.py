@@ -19,6 +19,12 @@ MAX_PARTS = 1024
 ATTN_NPARAM = 48 * 16 + 48 + 16 * 16 + 16 + 16 + 16
 
 
+def attn_nparam(E):
+    """Floats in one attention parameter block for token width E: in_proj (3E x E + 3E), out_proj (E x E + E),
+    LayerNorm (2E)."""
+    return 4 * E * E + 6 * E
+
+
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -442,20 +448,27 @@ class HipOps:
                                                 self._stream()), "cg_tok_wgrad_reduce")
 
     # -- attention ------------------------------------------------------------------
+    # X, Y, dX, dY: (cells * 16, E) token rows; E = latent_dim / 16
     def attn_fwd(self, Y, X, keep, params, heads):
-        n_cells = X.numel() // 256
-        assert X.is_contiguous() and Y.is_contiguous() and params.numel() == ATTN_NPARAM
+        E = X.shape[-1]
+        n_cells = X.numel() // (16 * E)
+        assert X.is_contiguous() and Y.is_contiguous() and params.numel() == attn_nparam(E)
         assert keep is None or (keep.is_contiguous() and keep.numel() == n_cells * heads * 256)
-        st = self.lib.cg_attn_ln_fwd(_ptr(Y), _ptr(X), _ptr(keep), _ptr(params), n_cells, 16, heads, self._stream())
+        st = self.lib.cg_attn_ln_fwd(_ptr(Y), _ptr(X), _ptr(keep), _ptr(params), n_cells, E, heads, self._stream())
         _lib.check(st, "cg_attn_ln_fwd")
 
-    def attn_bwd_ws(self, n_cells):
-        return self.lib.cg_attn_bwd_blocks(n_cells) * ATTN_NPARAM
+    def attn_bwd_ws(self, n_cells, E=16, heads=4):
+        n = self.lib.cg_attn_bwd_ws(n_cells, E, heads)
+        if n < 0:
+            raise _lib.CgError(f"cg_attn_bwd_ws: token width {E} with {heads} heads is not built "
+                               "(widths 4, 8, 16, 32; heads dividing the width)")
+        return n
 
     def attn_bwd(self, dX, dparams, ws, dY, X, keep, params, heads, accumulate):
-        n_cells = X.numel() // 256
-        assert ws.numel() >= self.attn_bwd_ws(n_cells) and dparams.numel() == ATTN_NPARAM
+        E = X.shape[-1]
+        n_cells = X.numel() // (16 * E)
+        assert ws.numel() >= self.attn_bwd_ws(n_cells, E, heads) and dparams.numel() == attn_nparam(E)
         assert X.is_contiguous() and dY.is_contiguous() and dX.is_contiguous()
         st = self.lib.cg_attn_ln_bwd(_ptr(dX), _ptr(dparams), _ptr(ws), _ptr(dY), _ptr(X), _ptr(keep), _ptr(params),
-                                     n_cells, 16, heads, int(accumulate), self._stream())
+                                     n_cells, E, heads, int(accumulate), self._stream())
         _lib.check(st, "cg_attn_ln_bwd")

@@ -338,27 +338,35 @@ int cg_adam_amsgrad(float* p, const float* g, float* m, float* v, float* vmax, s
 /*
  * Fused token self-attention + LayerNorm of the generator bottleneck
  * (GeneSelfAttention.forward, GAN_functions.py:34-36, with
- * nn.MultiheadAttention(16, 4, dropout=0.1, batch_first=True) on its
- * need_weights=True path).  Per cell X is (16 tokens, 16 features), 4 heads:
- *   qkv = X Win^T + bin; A = softmax(q k^T / 2); P = A * keep;
+ * nn.MultiheadAttention(E, heads, dropout=0.1, batch_first=True) on its
+ * need_weights=True path; E = latent_dim / 16 and heads come from the config,
+ * GAN_functions.py:82,:103-113).  Per cell X is (16 tokens, E features):
+ *   qkv = X Win^T + bin; A = softmax(q k^T / sqrt(E / heads)); P = A * keep;
  *   o = concat_heads(P v) Wout^T + bout;  Y = LayerNorm(X + o)   (eps 1e-5)
  * keep (NULL in eval mode) is the dropout keep-mask already divided by 0.9,
- * laid out (cell*4 + head, 16, 16).  `params` is one block of CG_ATTN_NPARAM
- * floats: Win[48][16] | bin[48] | Wout[16][16] | bout[16] | ln_w[16] | ln_b[16]
- * (the order of the module's state_dict).  Only E = 16, heads = 4 is built;
- * anything else returns CG_ERR_UNSUPPORTED.
+ * laid out (cell*heads + head, 16, 16).  `params` is one block of
+ * CG_ATTN_NPARAM_E(E) floats: Win[3E][E] | bin[3E] | Wout[E][E] | bout[E] |
+ * ln_w[E] | ln_b[E] (the order of the module's state_dict).  E = 16 with 4
+ * heads (the reference's default, GAN_main.py:52-53) has a kernel of its own,
+ * one wave per cell with everything in registers; E in {4, 8, 16, 32} with any
+ * head count dividing E runs a general kernel (one wave per workgroup, stages
+ * exchanged through LDS).  Anything else returns CG_ERR_UNSUPPORTED.
  */
-#define CG_ATTN_NPARAM (48 * 16 + 48 + 16 * 16 + 16 + 16 + 16)
+#define CG_ATTN_NPARAM_E(E) (4 * (E) * (E) + 6 * (E))
+#define CG_ATTN_NPARAM CG_ATTN_NPARAM_E(16)
 int cg_attn_ln_fwd(float* Y, const float* X, const float* keep, const float* params, int n_cells, int E, int heads,
                    void* stream);
 /*
  * Backward of cg_attn_ln_fwd; the forward is recomputed from X and keep, so no
  * activations are saved.  dX receives the input gradient; parameter gradients
- * are summed per workgroup into `wpart` (cg_attn_bwd_blocks(n_cells) x
- * CG_ATTN_NPARAM floats of caller workspace) and then in workgroup order into
- * dparams (same layout as params), `accumulate` adding to what is there.
+ * are summed per workgroup into `wpart` (cg_attn_bwd_ws(n_cells, E, heads)
+ * floats of caller workspace; -1 for a geometry that is not built) and then in
+ * workgroup order into dparams (same layout as params), `accumulate` adding to
+ * what is there.  cg_attn_bwd_blocks(n_cells) * CG_ATTN_NPARAM is the same
+ * figure for E = 16, heads = 4.
  */
 int cg_attn_bwd_blocks(int n_cells);
+long long cg_attn_bwd_ws(int n_cells, int E, int heads);
 int cg_attn_ln_bwd(float* dX, float* dparams, float* wpart, const float* dY, const float* X, const float* keep,
                    const float* params, int n_cells, int E, int heads, int accumulate, void* stream);
 

@@ -10,6 +10,8 @@ The product never imports this file.
 """
 from __future__ import annotations
 
+import math
+
 import torch
 
 EPI_NONE, EPI_LEAKY, EPI_MUL = 0, 1, 2
@@ -351,29 +353,30 @@ class CpuOps:
 
     # -- attention + LayerNorm (cg_attn_ln_fwd / cg_attn_ln_bwd) ---------------------------------
     @staticmethod
-    def _attn_params(params):
+    def _attn_params(params, E=16):
         o = 0
         out = []
-        for n, shape in ((768, (48, 16)), (48, (48,)), (256, (16, 16)), (16, (16,)), (16, (16,)), (16, (16,))):
+        for n, shape in ((3 * E * E, (3 * E, E)), (3 * E, (3 * E,)), (E * E, (E, E)), (E, (E,)), (E, (E,)), (E, (E,))):
             out.append(params[o:o + n].reshape(shape))
             o += n
         return out
 
     def _attn_forward(self, X, keep, params, heads):
-        Win, bin_, Wout, bout, lnw, lnb = self._attn_params(params)
-        b = X.numel() // 256
-        x = X.reshape(b, 16, 16)
-        hd = 16 // heads
+        E = X.shape[-1]
+        Win, bin_, Wout, bout, lnw, lnb = self._attn_params(params, E)
+        b = X.numel() // (16 * E)
+        x = X.reshape(b, 16, E)
+        hd = E // heads
         qkv = x @ Win.t() + bin_
-        q, k, v = qkv[..., :16], qkv[..., 16:32], qkv[..., 32:]
+        q, k, v = qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:]
 
         def hs(t):
             return t.reshape(b, 16, heads, hd).permute(0, 2, 1, 3).reshape(b * heads, 16, hd)
-        q, k, v = hs(q) * 0.5, hs(k), hs(v)
+        q, k, v = hs(q) * math.sqrt(1.0 / hd), hs(k), hs(v)
         att = torch.softmax(q @ k.transpose(1, 2), dim=-1)
         if keep is not None:
             att = att * keep.reshape(b * heads, 16, 16)
-        o = (att @ v).reshape(b, heads, 16, hd).permute(0, 2, 1, 3).reshape(b, 16, 16)
+        o = (att @ v).reshape(b, heads, 16, hd).permute(0, 2, 1, 3).reshape(b, 16, E)
         s = x + o @ Wout.t() + bout
         mean = s.mean(-1, keepdim=True)
         var = ((s - mean) ** 2).mean(-1, keepdim=True)
@@ -382,7 +385,9 @@ class CpuOps:
     def attn_fwd(self, Y, X, keep, params, heads):
         Y.copy_(self._attn_forward(X, keep, params, heads).reshape(Y.shape))
 
-    def attn_bwd_ws(self, n_cells):
+    def attn_bwd_ws(self, n_cells, E=16, heads=4):
+        if E not in (4, 8, 16, 32) or heads < 1 or E % heads:      # the geometries cg_attn_bwd_ws accepts
+            raise ValueError(f"token width {E} with {heads} heads is not built")
         return 1
 
     def attn_bwd(self, dX, dparams, ws, dY, X, keep, params, heads, accumulate):

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared_functions():
     text = open(os.path.join(ROOT, "include", "cgrna.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return set(re.findall(r"\b(?:int|size_t)\s+(cg_[a-z0-9_]+)\s*\(", text))
+    return set(re.findall(r"\b(?:int|size_t|long long)\s+(cg_[a-z0-9_]+)\s*\(", text))
 
 
 def test_library_exports_every_declared_symbol():

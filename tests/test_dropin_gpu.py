@@ -194,15 +194,17 @@ def _oracle_state(module):
     return {k: v.detach().cpu().clone() for k, v in module.state_dict().items()}
 
 
-@pytest.mark.parametrize("sparse,with_labels,gm,gh", [(False, False, 37, 50), (True, True, 64, 41)])
-def test_modules_against_oracle_edge_configurations(sparse, with_labels, gm, gh):
+@pytest.mark.parametrize("sparse,with_labels,gm,gh,latent,heads", [
+    (False, False, 37, 50, 256, 4), (True, True, 64, 41, 256, 4), (True, True, 45, 41, 128, 8), (False, True, 40, 40, 512, 4)])
+def test_modules_against_oracle_edge_configurations(sparse, with_labels, gm, gh, latent, heads):
     """cat_covs=None (zero embeddings, GAN_functions.py:136-137,182-183), the sparse-attention class
     (extra unused `gate` parameters), and gene counts that are odd / not multiples of 4 (unaligned
-    weight column slices take the scalar-load path of the GEMM)."""
+    weight column slices take the scalar-load path of the GEMM), other latent widths and head counts."""
     from cycle_gan_rna_amd import GAN_functions as F
     from cycle_gan_rna_amd.noise import HostReplayNoise
     from oracle import cyclegan_oracle as O
-    cfg = O.default_config(hidden_dims=[96, 64, 32], preprocess_type="log_normalized", use_sparse_attention=sparse)
+    cfg = O.default_config(hidden_dims=[96, 64, 32], preprocess_type="log_normalized", use_sparse_attention=sparse,
+                           latent_dim=latent, num_attention_heads=heads)
     g_m2h, g_h2m, d_m, d_h = build_modules(gm, gh, cfg, 5)
     if sparse:
         assert "residual_attention_blocks.0.1.gate.weight" in g_m2h.state_dict()
@@ -240,34 +242,35 @@ def test_modules_against_oracle_edge_configurations(sparse, with_labels, gm, gh)
             assert rel(params[k].grad, P[k].grad, floor) <= 1.0, (k, rel(params[k].grad, P[k].grad, floor))
 
 
-def test_standalone_blocks_match_torch_modules():
+@pytest.mark.parametrize("E,heads", [(16, 4), (8, 2), (32, 8), (16, 16), (4, 1)])
+def test_standalone_blocks_match_torch_modules(E, heads):
     """ResidualBlock and GeneSelfAttention used on their own (eval mode: no dropout) against the
     torch.nn layers they wrap, forward and backward."""
     from cycle_gan_rna_amd import GAN_functions as F
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
-    x = torch.randn(6, 16, 16)
-    rb = F.ResidualBlock(16).to(dev)
+    x = torch.randn(6, 16, E)
+    rb = F.ResidualBlock(E).to(dev)
     xr = x.to(dev).requires_grad_(True)
     y = rb(xr)                                     # train mode: batch statistics
     y.square().sum().backward()
     xc = x.clone().requires_grad_(True)
-    blk = torch.nn.Sequential(torch.nn.Linear(16, 16), torch.nn.BatchNorm1d(16), torch.nn.ReLU(), torch.nn.Linear(16, 16),
-                              torch.nn.BatchNorm1d(16))
+    blk = torch.nn.Sequential(torch.nn.Linear(E, E), torch.nn.BatchNorm1d(E), torch.nn.ReLU(), torch.nn.Linear(E, E),
+                              torch.nn.BatchNorm1d(E))
     sd = {k: v.cpu() for k, v in rb.block.state_dict().items()}
     sd["1.running_mean"].zero_(), sd["1.running_var"].fill_(1), sd["4.running_mean"].zero_(), sd["4.running_var"].fill_(1)
     blk.load_state_dict(sd)
-    ye = xc + blk(xc.view(96, 16)).view(6, 16, 16)
+    ye = xc + blk(xc.view(96, E)).view(6, 16, E)
     ye.square().sum().backward()
     assert rel(y, ye) <= 2e-4 and rel(xr.grad, xc.grad, 1e-3 * float(xc.grad.abs().max())) <= 1.0
     assert rel(rb.block[0].weight.grad, blk[0].weight.grad, 1e-3 * float(blk[0].weight.grad.abs().max())) <= 1.0
-    at = F.GeneSelfAttention(16, 4).to(dev).eval()
+    at = F.GeneSelfAttention(E, heads).to(dev).eval()
     xa = x.to(dev).requires_grad_(True)
     ya = at(xa)
     ya.square().sum().backward()
-    ref = torch.nn.MultiheadAttention(16, 4, dropout=0.1, batch_first=True).eval()
+    ref = torch.nn.MultiheadAttention(E, heads, dropout=0.1, batch_first=True).eval()
     ref.load_state_dict({k: v.cpu() for k, v in at.attention.state_dict().items()})
-    ln = torch.nn.LayerNorm(16)
+    ln = torch.nn.LayerNorm(E)
     ln.load_state_dict({k: v.cpu() for k, v in at.norm.state_dict().items()})
     xb = x.clone().requires_grad_(True)
     yb = ln(xb + ref(xb, xb, xb)[0])

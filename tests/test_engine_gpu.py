@@ -115,6 +115,26 @@ def check_updates(nets, tr, eng, tol):
             assert err <= tol, (n, k, err)
 
 
+@pytest.mark.parametrize("latent_dim,heads,blocks,hidden", [
+    (128, 2, 3, [96, 64, 32]), (512, 8, 2, [128, 64]), (256, 8, 5, [96, 64, 32]), (128, 8, 6, [64, 48, 32, 24]),
+    (512, 16, 4, [96, 64, 32])])
+def test_other_latent_geometries_match_oracle(ops, latent_dim, heads, blocks, hidden):
+    """latent_dim, num_attention_heads, residual_blocks and hidden_dims as a hyper-parameter search would set them
+    (GAN_functions.py:80-125 reads all four from the config)."""
+    cfg = O.default_config(preprocess_type="log_normalized", nb_critic=2, use_wandb=False, latent_dim=latent_dim,
+                           num_attention_heads=heads, residual_blocks=blocks, hidden_dims=hidden)
+    nets, tr, eng, exp, got = run_both(ops, cfg, 52, 44, 24, iters=3)      # generator steps at i = 0, 2
+    for i, (e, g) in enumerate(zip(exp, got)):
+        if not g:
+            continue
+        tol = 1e-4 if i == 0 else 5e-3
+        for k in LOSS_KEYS:
+            assert rel(g[k], e[k], FLOOR.get(k, 0.0)) <= tol, (i, k, g[k], e[k])
+        ftol = 1e-4 if i == 0 else 3e-2
+        assert rel(g["fake_human"], e["fake_human"]) <= ftol, (i, rel(g["fake_human"], e["fake_human"]))
+    check_updates(nets, tr, eng, 3e-1)
+
+
 def test_default_hidden_dims_one_iteration(ops):
     """Default architecture (2048/1024/512 hidden) at a modest gene count."""
     cfg = O.default_config(preprocess_type="log_normalized", nb_critic=1)

@@ -472,6 +472,78 @@ def test_attention_layernorm(ops, n_cells, train):
     close(dp, edp, 5e-5, "attn dparams")
 
 
+@pytest.mark.parametrize("E,heads,n_cells,train", [
+    (8, 2, 5, True), (8, 8, 64, True), (4, 1, 3, True), (4, 4, 700, True), (16, 8, 9, True), (16, 16, 33, False),
+    (16, 1, 2, True), (32, 4, 130, True), (32, 8, 512, True), (32, 16, 1, True), (32, 32, 17, False), (16, 2, 600, True)])
+def test_attention_layernorm_other_geometries(ops, E, heads, n_cells, train):
+    """Token width latent_dim / 16 and the head count come from the config (GAN_functions.py:82,:103-113): the
+    general kernel against the float64 restatement, more cells than workgroups included."""
+    from cycle_gan_rna_amd.ops import attn_nparam
+    npar = attn_nparam(E)
+    X = rnd(n_cells * 16, E, seed=1)
+    params = rnd(npar, seed=2) * 0.3
+    params[4 * E * E + 4 * E:4 * E * E + 5 * E] += 1.0            # LayerNorm weight around 1
+    g = torch.Generator().manual_seed(3)
+    keep = ((torch.rand(n_cells * heads, 16, 16, generator=g) < 0.9).float() / 0.9) if train else None
+    c64 = CpuOps(torch.float64)
+    eY = torch.empty(n_cells * 16, E, dtype=torch.float64)
+    c64.attn_fwd(eY, X.double(), None if keep is None else keep.double(), params.double(), heads)
+    Y = torch.empty(n_cells * 16, E).cuda()
+    ops.attn_fwd(Y, dev(X), dev(keep), dev(params), heads)
+    close(Y, eY, 2e-5, "attn fwd")
+    dY = rnd(n_cells * 16, E, seed=4)
+    edX, edp = torch.empty(n_cells * 16, E, dtype=torch.float64), torch.ones(npar, dtype=torch.float64)
+    c64.attn_bwd(edX, edp, None, dY.double(), X.double(), None if keep is None else keep.double(), params.double(),
+                 heads, True)
+    dX, dp = torch.empty(n_cells * 16, E).cuda(), torch.ones(npar).cuda()
+    ws = torch.empty(ops.attn_bwd_ws(n_cells, E, heads)).cuda()
+    ops.attn_bwd(dX, dp, ws, dev(dY), dev(X), dev(keep), dev(params), heads, True)
+    close(dX, edX, 5e-5, "attn dX")
+    close(dp, edp, 5e-5, "attn dparams")
+
+
+def test_attention_rejects_geometry_without_kernel(ops):
+    from cycle_gan_rna_amd._lib import CgError
+    with pytest.raises(CgError, match="is not built"):
+        ops.attn_bwd_ws(4, 12, 4)
+    with pytest.raises(CgError, match="is not built"):
+        ops.attn_bwd_ws(4, 16, 3)
+
+
+@pytest.mark.parametrize("D", [4, 8, 32])
+def test_token_residual_block_shapes_through_general_kernels(ops, D):
+    """(cells * 16, D) token matrices with D x D weights: the shapes the ResidualBlock (GAN_functions.py:55-71) hands
+    to cg_gemm / cg_bn_fwd / cg_bn_bwd when the token width is not 16."""
+    T = 16 * 96
+    X, W, b = rnd(T, D, seed=1), rnd(D, D, seed=2) * 0.4, rnd(D, seed=3)
+    gamma, beta = 1 + 0.1 * rnd(D, seed=4), 0.1 * rnd(D, seed=5)
+    c64 = CpuOps(torch.float64)
+    for slope in (0.0, 1.0):
+        eT, eY = torch.empty(T, D, dtype=torch.float64), torch.empty(T, D, dtype=torch.float64)
+        em, ei, erm, erv = (torch.zeros(D, dtype=torch.float64), torch.zeros(D, dtype=torch.float64),
+                            torch.zeros(D, dtype=torch.float64), torch.ones(D, dtype=torch.float64))
+        c64.gemm(eT, X.double(), W.double(), False, True, bias=b.double())
+        c64.bn_fwd(eY, eT, gamma.double(), beta.double(), em, ei, erm, erv, slope)
+        Tm, Y = torch.empty(T, D).cuda(), torch.empty(T, D).cuda()
+        m, i, rm, rv = torch.zeros(D).cuda(), torch.zeros(D).cuda(), torch.zeros(D).cuda(), torch.ones(D).cuda()
+        ops.gemm(Tm, dev(X), dev(W), False, True, bias=dev(b))
+        ops.bn_fwd(Y, Tm, dev(gamma), dev(beta), m, i, rm, rv, slope)
+        close(Tm, eT, 2e-5, "token linear")
+        close(Y, eY, 5e-5, "token batchnorm")
+        close(rv, erv, 1e-5, "running_var")
+        dY = rnd(T, D, seed=6)
+        edX, edg, edb = torch.empty(T, D, dtype=torch.float64), torch.zeros(D, dtype=torch.float64), torch.zeros(D, dtype=torch.float64)
+        c64.bn_bwd(edX, dY.double(), eT, eY, None, em, ei, gamma.double(), edg, edb, True, slope)
+        dX, dg, db = torch.empty(T, D).cuda(), torch.zeros(D).cuda(), torch.zeros(D).cuda()
+        ops.bn_bwd(dX, dev(dY), Tm, Y, None, m, i, dev(gamma), dg, db, True, slope)
+        close(dX, edX, 1e-4, "token batchnorm dX")
+        close(dg, edg, 1e-4, "token batchnorm dgamma")
+        edW, dW = torch.zeros(D, D, dtype=torch.float64), torch.zeros(D, D).cuda()
+        c64.gemm(edW, edX, X.double(), True, False, accumulate=True)
+        ops.gemm(dW, dX, dev(X), True, False, accumulate=True)
+        close(dW, edW, 1e-4, "token weight gradient")
+
+
 @pytest.mark.parametrize("M,N,K,ta,tb,epi,acc", [
     (512, 12, 1024, 0, 0, EPI_NONE, 0), (1536, 1, 256, 0, 1, EPI_NONE, 0), (1, 256, 1024, 1, 0, EPI_NONE, 1),
     (512, 256, 1, 0, 0, EPI_MUL, 0), (300, 7, 100, 0, 0, EPI_LEAKY, 0), (130, 1024, 12, 0, 1, EPI_NONE, 1),
