@@ -22,7 +22,7 @@ Z = C.c_size_t
 
 class GlossDesc(C.Structure):
     _fields_ = [("n_terms", C.c_int * 5), ("slot", (C.c_int * 4) * 5), ("weight", (C.c_double * 4) * 5),
-                ("lambda_", C.c_double * 5), ("ema_alpha", C.c_double)]
+                ("lambda_", C.c_double * 5), ("ema_alpha", C.c_double), ("weights", C.c_void_p)]
 
 
 SIGNATURES = {
@@ -57,12 +57,14 @@ SIGNATURES = {
     "cg_gp_penalty": ([P, I, P, P, I, F, I, I, P], I),
     "cg_reduce_sum": ([P, P, P, I, I, I, P], I),
     "cg_reduce_l1": ([P, P, P, I, P, I, I, I, P], I),
+    "cg_reduce_poisson": ([P, P, P, I, P, I, I, I, P], I),
     "cg_reduce_centroid_sq": ([P, P, P, I, P, I, P, I, I, I, I, P], I),
     "cg_reduce_kl": ([P, P, P, I, I, I, P], I),
     "cg_colsum": ([P, P, I, I, I, F, I, P], I),
     "cg_reduce_sqdiff": ([P, P, P, I, P, I, I, I, P], I),
     "cg_colvar_mean": ([P, P, P, I, I, I, P], I),
     "cg_l1_bwd": ([P, I, P, I, P, I, P, I, F, I, I, I, P], I),
+    "cg_poisson_bwd": ([P, I, P, I, P, I, P, I, F, I, I, I, P], I),
     "cg_centroid_bwd": ([P, I, P, I, P, I, P, I, P, I, F, I, I, I, I, P], I),
     "cg_fm_bwd": ([P, I, P, P, P, I, F, I, I, I, P], I),
     "cg_gloss_finalize": ([P, P, P, P, P, C.POINTER(GlossDesc), P], I),

@@ -193,6 +193,18 @@ __global__ void __launch_bounds__(256) reduce_l1_kernel(float* parts, int* npart
   write_part(s, parts, nparts);
 }
 
+// Poisson negative log-likelihood up to the target-only term, poisson_loss (GAN_functions.py:216-217):
+// sum of pred - target * log(pred + 1e-10)
+__global__ void __launch_bounds__(256) reduce_poisson_kernel(float* parts, int* nparts, const float* A, int lda,
+                                                             const float* B, int ldb, int M, int N) {
+  float s = 0.f;
+  CG_2D_LOOP(M, N) {
+    const float pr = A[(size_t)m * lda + col];
+    s += pr - B[(size_t)m * ldb + col] * logf(pr + 1e-10f);
+  }
+  write_part(s, parts, nparts);
+}
+
 __device__ __forceinline__ int64_t clamp_label(int64_t t, int n_types) {
   return t < 0 ? 0 : (t >= n_types ? n_types - 1 : t);
 }
@@ -295,6 +307,16 @@ __global__ void l1_bwd_kernel(float* dA, int ldd, const float* A, int lda, const
   }
 }
 
+__global__ void poisson_bwd_kernel(float* dA, int ldd, const float* A, int lda, const float* B, int ldb,
+                                   const float* coef, int idx, float scale, int M, int N, int accumulate) {
+  const float k = coef[idx] * scale;
+  CG_2D_LOOP(M, N) {
+    const float g = k * (1.f - B[(size_t)m * ldb + col] / (A[(size_t)m * lda + col] + 1e-10f));
+    float* o = dA + (size_t)m * ldd + col;
+    *o = accumulate ? *o + g : g;
+  }
+}
+
 __global__ void centroid_bwd_kernel(float* dA, int ldd, const float* A, int lda, const float* Cn, int ldc,
                                     const int64_t* labels, int lstride, const float* coef, int idx, float scale, int M,
                                     int N, int n_types, int accumulate) {
@@ -340,6 +362,18 @@ __global__ void __launch_bounds__(64) gloss_finalize_kernel(double* ema, double*
     L[k] = (double)acc;
   }
   if (threadIdx.x != 0) return;
+  if (d.weights) {      // weights given by the caller: no moving averages, no re-scaling
+    double g = 0.0;
+    for (int k = 0; k < 5; ++k) {
+      const float c = d.weights[k];
+      coef[k] = c;
+      g += (double)c * L[k];
+      losses[k] = L[k];
+      losses[6 + k] = 1.0;
+    }
+    losses[5] = g;
+    return;
+  }
   const double a = d.ema_alpha;
   double sc[5];
   for (int k = 0; k < 5; ++k) ema[k] = a * L[k] + (1.0 - a) * ema[k];
@@ -486,6 +520,14 @@ extern "C" int cg_reduce_l1(float* parts, int* nparts, const float* A, int lda, 
   return cg_launch_status();
 }
 
+extern "C" int cg_reduce_poisson(float* parts, int* nparts, const float* pred, int ldp, const float* target, int ldt,
+                                 int M, int N, void* stream) {
+  if (!parts || !nparts || !pred || !target || M <= 0 || N <= 0 || ldp < N || ldt < N) return CG_ERR_BAD_ARG;
+  Grid2 g = grid_red(M, N);
+  hipLaunchKernelGGL(reduce_poisson_kernel, g.grid, g.block, 0, ST, parts, nparts, pred, ldp, target, ldt, M, N);
+  return cg_launch_status();
+}
+
 extern "C" int cg_reduce_centroid_sq(float* parts, int* nparts, const float* A, int lda, const float* Cn, int ldc,
                                      const int64_t* labels, int lstride, int M, int N, int n_types, void* stream) {
   if (!parts || !nparts || !A || !Cn || !labels || M <= 0 || N <= 0 || lda < N || ldc < N || lstride < 1 || n_types < 1)
@@ -532,6 +574,15 @@ extern "C" int cg_l1_bwd(float* dA, int ldd, const float* A, int lda, const floa
   Grid2 g = grid2(M, N);
   hipLaunchKernelGGL(l1_bwd_kernel, g.grid, g.block, 0, ST, dA, ldd, A, lda, B, ldb, coef, idx, scale, M, N,
                      accumulate);
+  return cg_launch_status();
+}
+
+extern "C" int cg_poisson_bwd(float* dA, int ldd, const float* pred, int ldp, const float* target, int ldt,
+                              const float* coef, int idx, float scale, int M, int N, int accumulate, void* stream) {
+  if (!dA || !pred || !target || !coef || M <= 0 || N <= 0 || ldd < N || ldp < N || ldt < N) return CG_ERR_BAD_ARG;
+  Grid2 g = grid2(M, N);
+  hipLaunchKernelGGL(poisson_bwd_kernel, g.grid, g.block, 0, ST, dA, ldd, pred, ldp, target, ldt, coef, idx, scale, M,
+                     N, accumulate);
   return cg_launch_status();
 }
 

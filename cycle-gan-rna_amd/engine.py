@@ -781,8 +781,15 @@ class EngineBase:
         ev.record(torch.cuda.current_stream(self.ops.device))
         ring["done"][i] = ev
 
+    # betas (0.5, 0.9) with amsgrad: GAN_functions.py:223-225.  A subclass (or its config) may ask for torch.optim.Adam's
+    # defaults instead, as GAN_optimize_optuna.ipynb cell-1 (train_with_curriculum) builds its optimizers.
+    adam_betas = (0.5, 0.9)
+    adam_amsgrad = True
+
     def _adam(self, arena):
-        self.ops.adam(arena.p, arena.g, arena.m, arena.v, arena.vmax, arena.lr_step, 0.5, 0.9, 1e-8)
+        b1, b2 = self.adam_betas
+        self.ops.adam(arena.p, arena.g, arena.m, arena.v, arena.vmax if self.adam_amsgrad else None, arena.lr_step,
+                      float(b1), float(b2), 1e-8)
 
     # ---- HIP graphs ------------------------------------------------------------------
     def enable_graphs(self):
@@ -863,7 +870,16 @@ class StepEngine(EngineBase):
             for k in order[n]:
                 net.P[k].copy_(ops.to_device(split[n][0][k].detach().float()))
             self.nets[n] = net
-        self.lr_g = cfg["lr"] * 1.5          # GAN_functions.py:223
+        # opt-in departures from GAN_functions.py for the curriculum training of GAN_optimize_optuna.ipynb cell-1
+        # (absent keys = the reference's step): plain Adam with the config's betas, one lr for all three
+        # optimizers, Poisson cycle loss, loss weights handed in per epoch
+        if "adam_betas" in cfg:
+            self.adam_betas = tuple(cfg["adam_betas"])
+        self.adam_amsgrad = bool(cfg.get("adam_amsgrad", True))
+        self.cycle_poisson = cfg.get("cycle_loss", "l1") == "poisson"
+        assert cfg.get("cycle_loss", "l1") in ("l1", "poisson")
+        self.ext_weights = None              # set_loss_weights()
+        self.lr_g = cfg["lr"] * float(cfg.get("g_lr_mult", 1.5))          # GAN_functions.py:223
         self.lr_d = cfg["lr"]                # :224-225
         self.mouse_centroids = ops.to_device(mouse_centroids.float()).contiguous()
         self.human_centroids = ops.to_device(human_centroids.float()).contiguous()
@@ -1091,7 +1107,10 @@ class StepEngine(EngineBase):
 
         def cyc(key, p, x, lab, target, slot):
             o[key] = p.forward(x, lab, noise)                               # :349-357
-            ops.reduce_l1(red, slot, o[key], target)
+            if self.cycle_poisson:                                          # poisson_loss, :216-217
+                ops.reduce_poisson(red, slot, o[key], target)
+            else:
+                ops.reduce_l1(red, slot, o[key], target)
 
         def critics(name, fake, real, lab, cents, src_lab, s_adv, s_ct, m_real, m_fake, s_fm, gen_first, s_kl):
             # segments: adversarial call on the generated batch (:347) | feature call on it (:368,:371) | feature
@@ -1145,6 +1164,7 @@ class StepEngine(EngineBase):
         b = bl
         desc["lambda"] = [float(cfg["lambda_adv"]), float(cfg["lambda_cycle"]), float(cfg["lambda_celltype"]),
                           float(cfg["lambda_fm"]), float(cfg["lambda_kl"])]
+        desc["weights"] = self.ext_weights
         ops.gloss_finalize(self.ema, self.gloss, self.coef, red, desc)     # :380-406
         coef = self.coef
         # ---- backward.  Human side: everything that produces d(loss)/d(fake_human) (and g_h2m's gradients through
@@ -1157,7 +1177,10 @@ class StepEngine(EngineBase):
             gs.backward_input(b, coef, 0, -1.0 / b, dfe, dfake)
 
         def cycb(drec, recov, target, tdim, R, dx):
-            ops.l1_bwd(drec, recov, target, coef, 1, 1.0 / (b * tdim))
+            if self.cycle_poisson:
+                ops.poisson_bwd(drec, recov, target, coef, 1, 1.0 / (b * tdim))
+            else:
+                ops.l1_bwd(drec, recov, target, coef, 1, 1.0 / (b * tdim))
             R.backward(drec, need_dx=True, dx_out=dx)
         dch, dcm = self.d_cyc["human"][:b], self.d_cyc["mouse"][:b]
         self._many(lambda: crit(dfh, fake_human, self.human_centroids, mouse_cat, gh, self.gstack["d_h"], "h_fake",
@@ -1183,6 +1206,20 @@ class StepEngine(EngineBase):
         ops.colvar_mean(self.var_out[1:2], self.var_ws, fake_mouse)
         self.fake_human, self.fake_mouse = fake_human, fake_mouse
 
+    def set_loss_weights(self, weights):
+        """Five loss weights (adv, cycle, celltype, fm, kl) used as they are from now on, in place of
+        lambda_k x the moving-average scales of GAN_functions.py:380-406: the per-epoch curriculum weights
+        x epoch-level scales of GAN_optimize_optuna.ipynb cell-1 (get_curriculum_weights, train_epoch).  They
+        live in device memory, so a captured generator step picks up new values without a new capture.  Call
+        before the first generator step (a step captured without them keeps the moving-average rule)."""
+        w = torch.tensor([float(x) for x in weights], dtype=torch.float32)
+        assert w.numel() == 5
+        if self.ext_weights is None:
+            assert not any(str(k).startswith("g") for k in getattr(self, "_graphs", {})), \
+                "set_loss_weights() after a generator step was captured"
+            self.ext_weights = self.ops.zeros(5)
+        self.ext_weights.copy_(self.ops.to_device(w))
+
     def g_losses(self):
         t = self.gloss.cpu()
         v = self.var_out.cpu()
@@ -1192,12 +1229,17 @@ class StepEngine(EngineBase):
                     scales=dict(adv=float(t[6]), cycle=float(t[7]), celltype=float(t[8]), fm=float(t[9]), kl=float(t[10])),
                     fake_human_var=float(v[0]), fake_mouse_var=float(v[1]))
 
-    def iteration(self, i, mouse, human, mouse_cat, human_cat, noise, nxt=None, metrics=True):
+    def iteration(self, i, mouse, human, mouse_cat, human_cat, noise, nxt=None, metrics=True, critic=True):
         """One pass of the loop body :298-419; returns the metrics the reference
         records (only on generator steps, like :411-419).  `nxt`: the next iteration's
         (mouse, human, mouse_cat, human_cat), used only after enable_lookahead().  metrics=False skips the
-        device-to-host read of the losses (the host then never waits for the device)."""
-        if self.lookahead and not self.sync.enabled:
+        device-to-host read of the losses (the host then never waits for the device).  critic=False skips the
+        critic step (GAN_optimize_optuna.ipynb cell-1, train_epoch: critics train only while lambda_adv > 0)."""
+        if not critic:          # a curriculum phase without adversarial term trains the generators only
+            assert not self.lookahead
+            if i % self.cfg["nb_critic"] == 0:
+                self.g_step(mouse, human, mouse_cat, human_cat, noise)
+        elif self.lookahead and not self.sync.enabled:
             self._iteration_lookahead(i, mouse, human, mouse_cat, human_cat, noise, nxt)
         else:
             self.d_step(mouse, human, mouse_cat, human_cat, noise)
@@ -1205,7 +1247,8 @@ class StepEngine(EngineBase):
                 self.g_step(mouse, human, mouse_cat, human_cat, noise)
         out = {}
         if metrics and i % self.cfg["nb_critic"] == 0:
-            out.update(self.d_losses())
+            if critic:
+                out.update(self.d_losses())
             out.update(self.g_losses())
         return out
 

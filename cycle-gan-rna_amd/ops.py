@@ -336,6 +336,18 @@ class HipOps:
         st = self.lib.cg_colvar_mean(_ptr(out), _ptr(ws), _ptr(X), _ld(X), M, N, self._stream())
         _lib.check(st, "cg_colvar_mean")
 
+    def reduce_poisson(self, red, slot, pred, target):
+        M, N = pred.shape
+        p, n = self._slot(red, slot)
+        st = self.lib.cg_reduce_poisson(p, n, _ptr(pred), _ld(pred), _ptr(target), _ld(target), M, N, self._stream())
+        _lib.check(st, "cg_reduce_poisson")
+
+    def poisson_bwd(self, dA, pred, target, coef, idx, scale, accumulate=False):
+        M, N = pred.shape
+        st = self.lib.cg_poisson_bwd(_ptr(dA), _ld(dA), _ptr(pred), _ld(pred), _ptr(target), _ld(target), _ptr(coef),
+                                     idx, float(scale), M, N, int(accumulate), self._stream())
+        _lib.check(st, "cg_poisson_bwd")
+
     def l1_bwd(self, dA, A, B, coef, idx, scale, accumulate=False):
         M, N = A.shape
         st = self.lib.cg_l1_bwd(_ptr(dA), _ld(dA), _ptr(A), _ld(A), _ptr(B), _ld(B), _ptr(coef), idx, float(scale), M,
@@ -366,6 +378,9 @@ class HipOps:
                 d.weight[k][j] = w
             d.lambda_[k] = desc["lambda"][k]
         d.ema_alpha = desc["ema_alpha"]
+        w = desc.get("weights")
+        assert w is None or (w.dtype == torch.float32 and w.numel() == 5 and w.is_contiguous())
+        d.weights = _ptr(w)
         assert ema.dtype == torch.float64 and losses.dtype == torch.float64 and losses.numel() >= 11
         st = self.lib.cg_gloss_finalize(_ptr(ema), _ptr(losses), _ptr(coef), _ptr(parts), _ptr(nparts), C.byref(d),
                                         self._stream())
@@ -380,9 +395,10 @@ class HipOps:
 
     # -- optimizer ------------------------------------------------------------------
     def adam(self, p, g, m, v, vmax, lr_step, beta1, beta2, eps):
+        """vmax None: plain Adam (no running maximum of v)."""
         assert lr_step.dtype == torch.float64 and lr_step.numel() == 2
         n = p.numel()
-        assert g.numel() == n and m.numel() == n and v.numel() == n and vmax.numel() == n
+        assert g.numel() == n and m.numel() == n and v.numel() == n and (vmax is None or vmax.numel() == n)
         st = self.lib.cg_adam_amsgrad(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(vmax), n, _ptr(lr_step), beta1, beta2,
                                       eps, None, self._stream())
         _lib.check(st, "cg_adam_amsgrad")

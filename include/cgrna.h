@@ -224,6 +224,10 @@ int cg_gp_penalty(float* V, int ldv, float* rowpen, const float* UX, int ldu, fl
 int cg_reduce_sum(float* parts, int* nparts, const float* X, int ldx, int M, int N, void* stream);
 /* sum |A - B| (L1 cycle loss :353-357). */
 int cg_reduce_l1(float* parts, int* nparts, const float* A, int lda, const float* B, int ldb, int M, int N, void* stream);
+/* sum pred - target*log(pred + 1e-10): poisson_loss (GAN_functions.py:216-217) before its mean; the cycle term of
+ * the hyper-parameter search on counts data (GAN_optimize_optuna.ipynb cell-1, train_epoch). */
+int cg_reduce_poisson(float* parts, int* nparts, const float* pred, int ldp, const float* target, int ldt, int M, int N,
+                      void* stream);
 /* sum (A[m,:] - C[labels[m],:])^2 (cell-type centroid MSE :359-364); labels are clamped to [0, n_types). */
 int cg_reduce_centroid_sq(float* parts, int* nparts, const float* A, int lda, const float* C, int ldc,
                           const int64_t* labels, int lstride, int M, int N, int n_types, void* stream);
@@ -242,6 +246,9 @@ int cg_colvar_mean(float* out, double* strip_ws, const float* X, int ldx, int M,
 /* dA = coef[idx]*scale*sign(A-B) (gradient of the L1 term); dA may alias A. */
 int cg_l1_bwd(float* dA, int ldd, const float* A, int lda, const float* B, int ldb,
               const float* coef, int idx, float scale, int M, int N, int accumulate, void* stream);
+/* dA (+)= coef[idx]*scale*(1 - target/(pred + 1e-10)): gradient of poisson_loss (GAN_functions.py:216-217) w.r.t. pred. */
+int cg_poisson_bwd(float* dA, int ldd, const float* pred, int ldp, const float* target, int ldt,
+                   const float* coef, int idx, float scale, int M, int N, int accumulate, void* stream);
 /* dA (+)= coef[idx]*scale*(A[m,:] - C[labels[m],:]) (gradient of the centroid MSE). */
 int cg_centroid_bwd(float* dA, int ldd, const float* A, int lda, const float* C, int ldc,
                     const int64_t* labels, int lstride, const float* coef, int idx, float scale,
@@ -267,6 +274,9 @@ typedef struct {
   double weight[5][4];   /* loss_k = sum_j weight[k][j] * total(slot[k][j]) */
   double lambda[5];
   double ema_alpha;
+  const float* weights;  /* NULL, or 5 device floats used as coef_out as they are: no moving averages and no
+                            re-scaling (the per-epoch curriculum weights of GAN_optimize_optuna.ipynb cell-1,
+                            get_curriculum_weights x the epoch-level scales of train_epoch) */
 } cg_gloss_desc;
 int cg_gloss_finalize(double* ema_state, double* losses_out, float* coef_out, const float* parts,
                       const int* nparts, const cg_gloss_desc* desc, void* stream);
@@ -329,7 +339,9 @@ int cg_tok_wgrad_reduce(float* dW2, float* dW1, const float* wpart2, const float
  *   p -= (lr/(1-b1^t)) * m / (sqrt(vmax)/sqrt(1-b2^t) + eps)
  * lr_and_step: device array {lr, step t} as two doubles (so captured graphs can
  * be replayed with a new lr / step).  p_bf16 (may be NULL) receives the updated
- * parameters rounded to bf16.
+ * parameters rounded to bf16.  vmax NULL: no running maximum, the denominator
+ * uses v (torch.optim.Adam's default, as GAN_optimize_optuna.ipynb cell-1,
+ * train_with_curriculum builds its optimizers).
  */
 int cg_adam_amsgrad(float* p, const float* g, float* m, float* v, float* vmax, size_t n,
                     const double* lr_and_step, float beta1, float beta2, float eps,

@@ -275,7 +275,8 @@ class AdamAmsgrad:
     as torch's single-tensor loop executes it; parameters whose grad is None are
     skipped and keep their step count."""
 
-    def __init__(self, params: List[Tensor], lr: float, betas=(0.5, 0.9), eps=1e-8):
+    def __init__(self, params: List[Tensor], lr: float, betas=(0.5, 0.9), eps=1e-8, amsgrad=True):
+        self.amsgrad = amsgrad      # False: torch.optim.Adam's default (GAN_optimize_optuna.ipynb cell-1)
         self.params = params
         self.lr = lr
         self.b1, self.b2 = betas
@@ -299,10 +300,11 @@ class AdamAmsgrad:
             t = st["step"]
             st["m"].lerp_(g, 1 - self.b1)
             st["v"].mul_(self.b2).addcmul_(g, g, value=1 - self.b2)
-            torch.maximum(st["vmax"], st["v"], out=st["vmax"])
+            if self.amsgrad:
+                torch.maximum(st["vmax"], st["v"], out=st["vmax"])
             bc1 = 1 - self.b1 ** t
             bc2 = 1 - self.b2 ** t
-            denom = (st["vmax"].sqrt() / math.sqrt(bc2)).add_(self.eps)
+            denom = ((st["vmax"] if self.amsgrad else st["v"]).sqrt() / math.sqrt(bc2)).add_(self.eps)
             p.addcdiv_(st["m"], denom, value=-(self.lr / bc1))
 
 
@@ -348,14 +350,24 @@ class OracleTrainer:
                 P[k].requires_grad_(True)
             self.nets[name] = P
         gm, gh = self.nets["g_m2h"], self.nets["g_h2m"]
-        # :223-225 - one optimizer over both generators (m2h first), lr*1.5
-        self.opt_g = AdamAmsgrad([gm[k] for k in param_names(gm)] + [gh[k] for k in param_names(gh)], cfg["lr"] * 1.5)
-        self.opt_dm = AdamAmsgrad([self.nets["d_m"][k] for k in param_names(self.nets["d_m"])], cfg["lr"])
-        self.opt_dh = AdamAmsgrad([self.nets["d_h"][k] for k in param_names(self.nets["d_h"])], cfg["lr"])
+        # :223-225 - one optimizer over both generators (m2h first), lr*1.5.  The opt-in keys restate the curriculum
+        # training of GAN_optimize_optuna.ipynb cell-1 (plain Adam with the config's betas, one lr, Poisson cycle
+        # loss, loss weights handed in per epoch); absent keys = the reference's step.
+        kw = dict(betas=tuple(cfg.get("adam_betas", (0.5, 0.9))), amsgrad=bool(cfg.get("adam_amsgrad", True)))
+        self.opt_g = AdamAmsgrad([gm[k] for k in param_names(gm)] + [gh[k] for k in param_names(gh)],
+                                 cfg["lr"] * float(cfg.get("g_lr_mult", 1.5)), **kw)
+        self.opt_dm = AdamAmsgrad([self.nets["d_m"][k] for k in param_names(self.nets["d_m"])], cfg["lr"], **kw)
+        self.opt_dh = AdamAmsgrad([self.nets["d_h"][k] for k in param_names(self.nets["d_h"])], cfg["lr"], **kw)
+        self.cycle_poisson = cfg.get("cycle_loss", "l1") == "poisson"
+        self.ext_weights = None
         self.mouse_centroids = mouse_centroids
         self.human_centroids = human_centroids
         self.ema = dict(adv=0.0, cycle=0.0, celltype=0.0, fm=0.0, kl=0.0)   # :283-287
         self.scales = None
+
+    def set_loss_weights(self, weights):
+        """(adv, cycle, celltype, fm, kl) weights used as they are, rounded to float32 like the device copy."""
+        self.ext_weights = [float(torch.tensor(float(w), dtype=torch.float32)) for w in weights]
 
     def set_lr(self, lr):
         for o in (self.opt_g, self.opt_dm, self.opt_dh):        # :244-246
@@ -401,7 +413,10 @@ class OracleTrainer:
         g_adv = -self.D("d_h", fake_human, human_cat)[0].mean() - self.D("d_m", fake_mouse, mouse_cat)[0].mean()
         recov_mouse, _, _ = self.G("g_h2m", fake_human, human_cat)
         recov_human, _, _ = self.G("g_m2h", fake_mouse, mouse_cat)
-        g_cycle = (recov_mouse - mouse).abs().mean() + (recov_human - human).abs().mean()
+        if self.cycle_poisson:
+            g_cycle = poisson_loss(recov_mouse, mouse) + poisson_loss(recov_human, human)
+        else:
+            g_cycle = (recov_mouse - mouse).abs().mean() + (recov_human - human).abs().mean()
         g_celltype = torch.zeros((), dtype=mouse.dtype)
         if mouse_cat.shape[0] > 0 and human_cat.shape[0] > 0:   # :360-364
             g_celltype = g_celltype + F.mse_loss(fake_human, self.human_centroids[mouse_cat[:, 0]])
@@ -416,6 +431,16 @@ class OracleTrainer:
         kl = -0.5 * torch.mean(1 + lv_h - mu_h.pow(2) - lv_h.exp()) \
              - 0.5 * torch.mean(1 + lv_m - mu_m.pow(2) - lv_m.exp())   # :375-376
 
+        if self.ext_weights is not None:
+            w = self.ext_weights
+            g_loss = w[0] * g_adv + w[1] * g_cycle + w[2] * g_celltype + w[3] * g_fm + w[4] * kl
+            g_loss.backward()
+            self.opt_g.step()
+            return dict(g_loss=g_loss.item(), g_adv=g_adv.item(), cycle_loss=g_cycle.item(),
+                        celltype_loss=g_celltype.item(), fm_loss=g_fm.item(), kl_loss=kl.item(),
+                        fake_human_var=torch.var(fake_human.detach(), dim=0).mean().item(),
+                        fake_mouse_var=torch.var(fake_mouse.detach(), dim=0).mean().item(),
+                        fake_human=fake_human.detach(), fake_mouse=fake_mouse.detach())
         a = 0.3                                                  # :288, :380-384
         e = self.ema
         e["adv"] = a * g_adv.item() + (1 - a) * e["adv"]
@@ -440,9 +465,9 @@ class OracleTrainer:
                     scales=dict(s), ema=dict(e),
                     fake_human=fake_human.detach(), fake_mouse=fake_mouse.detach())
 
-    def iteration(self, i, mouse, human, mouse_cat, human_cat):
-        """One pass of the inner loop body, GAN_functions.py:298-419."""
-        out = self.d_step(mouse, human, mouse_cat, human_cat)
+    def iteration(self, i, mouse, human, mouse_cat, human_cat, critic=True):
+        """One pass of the inner loop body, GAN_functions.py:298-419 (critic=False: generators only)."""
+        out = self.d_step(mouse, human, mouse_cat, human_cat) if critic else {}
         if i % self.cfg["nb_critic"] == 0:                       # :342
             out.update(self.g_step(mouse, human, mouse_cat, human_cat))
         return out

@@ -278,6 +278,13 @@ class CpuOps:
     def reduce_l1(self, red, slot, A, B):
         self._put(red, slot, (A - B).abs().double().sum())
 
+    def reduce_poisson(self, red, slot, pred, target):
+        self._put(red, slot, (pred - target * torch.log(pred + 1e-10)).double().sum())
+
+    def poisson_bwd(self, dA, pred, target, coef, idx, scale, accumulate=False):
+        g = float(coef[idx]) * scale * (1 - target / (pred + 1e-10))
+        dA.copy_(dA + g if accumulate else g)
+
     def reduce_sqdiff(self, red, slot, A, B):
         self._put(red, slot, ((A - B) ** 2).double().sum())
 
@@ -321,6 +328,16 @@ class CpuOps:
             for slot, w in desc["terms"][k]:
                 acc = acc + torch.tensor(w * self._slot_total(red, slot), dtype=torch.float32)
             L.append(float(acc))
+        if desc.get("weights") is not None:
+            g = 0.0
+            for k in range(5):
+                c = float(desc["weights"][k])
+                coef[k] = c
+                g += c * L[k]
+                losses[k] = L[k]
+                losses[6 + k] = 1.0
+            losses[5] = g
+            return
         a = desc["ema_alpha"]
         for k in range(5):
             ema[k] = a * L[k] + (1 - a) * float(ema[k])
@@ -347,8 +364,9 @@ class CpuOps:
         bc2_sqrt = (1 - beta2 ** t) ** 0.5
         m.lerp_(g, 1 - beta1)
         v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
-        torch.maximum(vmax, v, out=vmax)
-        denom = (vmax.sqrt() / bc2_sqrt).add_(eps)
+        if vmax is not None:
+            torch.maximum(vmax, v, out=vmax)
+        denom = ((v if vmax is None else vmax).sqrt() / bc2_sqrt).add_(eps)
         p.addcdiv_(m, denom, value=-step_size)
 
     # -- attention + LayerNorm (cg_attn_ln_fwd / cg_attn_ln_bwd) ---------------------------------

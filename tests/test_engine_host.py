@@ -91,3 +91,45 @@ def test_engine_rejects_unsupported_geometry():
     nets, xm, xh, lm, lh = make_problem(40, 40, 12, cfg)
     with pytest.raises(Exception, match="is not built"):
         StepEngine(nets, cfg, O.centroid_table(xm, lm, 12), O.centroid_table(xh, lh, 12), CpuOps(), 12)
+
+
+def test_curriculum_options_equal_autograd_in_float64():
+    """Opt-in step variants of the curriculum training (GAN_optimize_optuna.ipynb cell-1, train_epoch): loss weights
+    handed in instead of the moving-average scales, Poisson cycle loss (GAN_functions.py:216-217) on counts data,
+    plain Adam with chosen betas and one learning rate, iterations without a critic step."""
+    from cycle_gan_rna_amd.engine import StepEngine
+    from cycle_gan_rna_amd.noise import HostReplayNoise
+    dtype = torch.float64
+    cfg = small_cfg(preprocess_type="counts", nb_critic=2, cycle_loss="poisson", adam_betas=(0.3, 0.95),
+                    adam_amsgrad=False, g_lr_mult=1.0)
+    nets, xm, xh, lm, lh = make_problem(40, 36, 12, cfg, dtype=dtype)
+    xm, xh = torch.expm1(xm).round(), torch.expm1(xh).round()          # count-like targets
+    cm, ch = O.centroid_table(xm, lm, 12), O.centroid_table(xh, lh, 12)
+    schedule = [([0.0, 7.5, 0.05, 0.0, 0.01], False), ([0.0, 7.5, 0.05, 0.0, 0.01], False),
+                ([0.1, 4.0, 0.2, 0.0, 0.05], True), ([0.1, 4.0, 0.2, 0.0, 0.05], True),
+                ([0.8, 3.0, 0.15, 0.25, 0.08], True)]
+    tr = O.OracleTrainer(nets, cfg, cm, ch)
+    eng = StepEngine(nets, cfg, cm, ch, CpuOps(dtype), 12)
+    torch.manual_seed(4)
+    exp = []
+    for i, (w, critic) in enumerate(schedule):
+        tr.set_loss_weights(w)
+        exp.append(tr.iteration(i, xm, xh, lm[:, None], lh[:, None], critic=critic))
+    torch.manual_seed(4)
+    got = []
+    for i, (w, critic) in enumerate(schedule):
+        eng.set_loss_weights(w)
+        got.append(eng.iteration(i, xm, xh, lm[:, None], lh[:, None], HostReplayNoise("cpu", dtype), critic=critic))
+    assert [bool(g) for g in got] == [True, False, True, False, True]
+    assert "d_m_loss" not in got[0] and "d_m_loss" in got[2]
+    for e, g in zip(exp, got):
+        for k in LOSS_KEYS:
+            if k in g:
+                assert rel(g[k], e[k]) <= 5e-7, (k, g[k], e[k])
+    for n in ("g_m2h", "g_h2m", "d_m", "d_h"):
+        sd = eng.state_dict(n)
+        for k, v in sd.items():
+            if O.is_gauge_param(k, sd):
+                continue
+            tol = 1e-4 if k.endswith("running_mean") else 5e-5
+            assert rel(v, tr.nets[n][k]) <= tol, (n, k, rel(v, tr.nets[n][k]))

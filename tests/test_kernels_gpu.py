@@ -449,6 +449,56 @@ def test_adam_matches_torch_optimizer(ops):
     close(p, ref.detach(), 1e-6, "adam p")
 
 
+def test_poisson_cycle_loss_weights_and_plain_adam(ops):
+    """Kernels of the curriculum training (GAN_optimize_optuna.ipynb cell-1): poisson_loss (GAN_functions.py:216-217)
+    and its gradient against autograd, loss weights taken as given, Adam without the running maximum."""
+    M, N = 130, 333
+    target = torch.poisson(torch.full((M, N), 0.4), generator=torch.Generator().manual_seed(1))
+    wide = rnd(M, N + 6, seed=2).abs() * 2
+    wide[:, 5] = 0.0                                  # pred = 0 where the library-size ReLU cut
+    pred = wide[:, 3:3 + N]
+    red = (torch.zeros(8, 1024).cuda(), torch.zeros(8, dtype=torch.int32).cuda())
+    ops.reduce_poisson(red, 1, dev(wide)[:, 3:3 + N], dev(target))
+    pr = pred.double().clone().requires_grad_(True)
+    loss = torch.mean(pr - target.double() * torch.log(pr + 1e-10))
+    loss.backward()
+    tot = torch.zeros(1, dtype=torch.float64).cuda()
+    ops.sum_parts(tot, red, dev(torch.tensor([1], dtype=torch.int32)), dev(torch.tensor([1.0 / (M * N)], dtype=torch.float64)))
+    assert abs(float(tot[0]) - float(loss.detach())) <= 2e-5 * abs(float(loss.detach())) + 1e-6
+    cf = torch.tensor([0.0, 3.0])
+    g = torch.ones(M, N).cuda()
+    ops.poisson_bwd(g, dev(wide)[:, 3:3 + N], dev(target), dev(cf), 1, 1.0 / (M * N), accumulate=True)
+    exp = 1.0 + 3.0 * pr.grad
+    big = exp.abs() > 1e3                             # target > 0 at pred = 0: 1e10-sized entries, compared relatively
+    assert float(((g.cpu().double() - exp)[~big]).abs().max()) <= 2e-5 * float(exp[~big].abs().max())
+    assert float(((g.cpu().double() - exp)[big] / exp[big]).abs().max()) <= 1e-5 if bool(big.any()) else True
+    # loss weights handed in: no moving averages, coefficients = the weights
+    desc = dict(terms=[[(1, 1.0)], [(1, 2.0)], [(1, 0.0)], [(1, -1.0)], [(1, 0.5)]], ema_alpha=0.3,
+                **{"lambda": [9.0] * 5})
+    w = torch.tensor([0.0, 7.5, 0.25, 0.0, 0.01])
+    desc["weights"] = dev(w)
+    ema = torch.full((5,), 3.0, dtype=torch.float64).cuda()
+    losses, coef = torch.zeros(11, dtype=torch.float64).cuda(), torch.zeros(5).cuda()
+    ops.gloss_finalize(ema, losses, coef, red, desc)
+    assert torch.equal(coef.cpu(), w) and torch.equal(ema.cpu(), torch.full((5,), 3.0, dtype=torch.float64))
+    L = losses.cpu()
+    assert abs(float(L[5]) - float((w.double() * L[:5]).sum())) <= 1e-9 * abs(float(L[5])) + 1e-12
+    # plain Adam
+    n = 5003
+    p0 = rnd(n, seed=1)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([ref], lr=2e-4, betas=(0.35, 0.96))
+    p, m, v = dev(p0.clone()), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+    lr_step = torch.zeros(2, dtype=torch.float64).cuda()
+    for t in range(1, 6):
+        gr = rnd(n, seed=10 + t) * (10.0 ** (3 - t))   # shrinking gradients: a running maximum would differ
+        ref.grad = gr.clone()
+        opt.step()
+        lr_step.copy_(torch.tensor([2e-4, float(t)], dtype=torch.float64))
+        ops.adam(p, dev(gr), m, v, None, lr_step, 0.35, 0.96, 1e-8)
+    close(p, ref.detach(), 1e-6, "plain adam p")
+
+
 @pytest.mark.parametrize("n_cells,train", [(1, True), (7, True), (512, True), (33, False)])
 def test_attention_layernorm(ops, n_cells, train):
     heads = 4
