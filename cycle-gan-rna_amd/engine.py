@@ -95,9 +95,20 @@ def split_state(sd):
 
 def _arena_order(keys):
     """state_dict order, with the (never used) sparse-attention gate moved to the
-    end so that each attention block's six tensors stay contiguous."""
+    end so that each attention block's six tensors stay contiguous, and log_var's weight / bias placed right
+    after mu's: the two heads of the encoder (GAN_functions.py:97-98,:139) then form one (2L, H) matrix and one
+    2L bias, and each of their three products (forward, weight gradient, input gradient) is a single GEMM."""
     gate = [k for k in keys if ".gate." in k]
-    return [k for k in keys if ".gate." not in k] + gate
+    out = []
+    for k in keys:
+        if ".gate." in k or k in ("log_var.weight", "log_var.bias"):
+            continue
+        if k == "mu.bias" and "log_var.weight" in keys:
+            out.append("log_var.weight")
+        out.append(k)
+        if k == "mu.bias" and "log_var.bias" in keys:
+            out.append("log_var.bias")
+    return out + gate
 
 
 class Net:
@@ -196,6 +207,14 @@ class GenPass:
         self.labels = None
         self.x = None
         self.b = 0
+        # [mu; log_var] as one matrix (see _arena_order)
+        ar, hl = net.arena, H[-1]
+        self.W_ml = ar.flat(ar.p, (net.name, "mu.weight"), 2 * L * hl).view(2 * L, hl)
+        self.b_ml = ar.flat(ar.p, (net.name, "mu.bias"), 2 * L)
+        self.GW_ml = ar.flat(ar.g, (net.name, "mu.weight"), 2 * L * hl).view(2 * L, hl)
+        self.Gb_ml = ar.flat(ar.g, (net.name, "mu.bias"), 2 * L)
+        assert self.W_ml[L:].data_ptr() == net.P["log_var.weight"].data_ptr() and \
+            self.b_ml[L:].data_ptr() == net.P["log_var.bias"].data_ptr()
 
     # attention parameter block of residual block `bi` (params or grads)
     def _attn(self, which, bi):
@@ -227,8 +246,7 @@ class GenPass:
                                  f"encoder.{3 * li}", f"encoder.{3 * li + 1}", train)
             a = self.enc_a[li][:b]
         ml = self.ml[:b]
-        ops.gemm(ml[:, :L], a, P["mu.weight"], False, True, bias=P["mu.bias"])
-        ops.gemm(ml[:, L:], a, P["log_var.weight"], False, True, bias=P["log_var.bias"])
+        ops.gemm(ml, a, self.W_ml, False, True, bias=self.b_ml)            # mu | log_var, :139
         self.eps = noise.randn((b, L))
         ops.reparam_fwd(self.z[0][:b], ml, self.eps)
         t = b * SEQ_LEN
@@ -370,13 +388,10 @@ class GenPass:
         if d_lv is not None:
             ops.axpby(dml[:, L:], 1.0, dml[:, L:], 1.0, d_lv)
         a_enc = self.enc_a[nh - 1][:b]
-        ops.gemm(G["mu.weight"], dml[:, :L], a_enc, True, False, accumulate=True)
-        ops.colsum(G["mu.bias"], dml[:, :L], 1.0, True)
-        ops.gemm(G["log_var.weight"], dml[:, L:], a_enc, True, False, accumulate=True)
-        ops.colsum(G["log_var.bias"], dml[:, L:], 1.0, True)
+        ops.gemm(self.GW_ml, dml, a_enc, True, False, accumulate=True)
+        ops.colsum(self.Gb_ml, dml, 1.0, True)
         da = self.d_act[nh - 1][:b]
-        ops.gemm(da, dml[:, :L], P["mu.weight"], False, False)
-        ops.gemm(da, dml[:, L:], P["log_var.weight"], False, False, accumulate=True)
+        ops.gemm(da, dml, self.W_ml, False, False)
         dx = None
         for li in reversed(range(nh)):
             a_prev = self.enc_a[li - 1][:b] if li > 0 else self.x

@@ -323,6 +323,9 @@ def test_hundred_iteration_trajectory_against_reference(precision):
     print(precision, {k: "%.1e" % v for k, v in worst.items()})
     for k in worst:
         if precision == "fp32":
-            assert first[k] <= 1e-3 and worst[k] <= 5e-2, (k, first[k], worst[k])
+            # smooth terms stay within 2e-2 over the 100 iterations; the adversarial ones (differences of critic
+            # outputs, and the feature-matching MSE of the critics' means, ~1e-3 in size) amplify rounding more:
+            # two float32 summation orders of this very build differ by up to 5e-2 there
+            assert first[k] <= 1e-3 and worst[k] <= (1e-1 if k in adversarial else 2e-2), (k, first[k], worst[k])
         else:
             assert first[k] <= 2e-2 and worst[k] <= (2e-1 if k in adversarial else 2e-2), (k, first[k], worst[k])
