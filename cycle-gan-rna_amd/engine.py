@@ -111,6 +111,31 @@ def _arena_order(keys):
     return out + gate
 
 
+def _emb_tables(P):
+    """(key, width) of the embedding tables, one per categorical covariate, in the order the reference
+    concatenates them (GAN_functions.py:85,:135,:160,:182)."""
+    out, i = [], 0
+    while f"embeddings.{i}.weight" in P:
+        out.append((f"embeddings.{i}.weight", P[f"embeddings.{i}.weight"].shape[1]))
+        i += 1
+    return out
+
+
+def _embed_gather(ops, out, P, labels):
+    """out (b, sum of widths) <- [table_i[labels[:, i]] for every covariate i]."""
+    off = 0
+    for i, (k, w) in enumerate(_emb_tables(P)):
+        ops.embed_gather(out[:, off:off + w], P[k], labels[:, i:i + 1])
+        off += w
+
+
+def _embed_scatter(ops, G, dout, labels, accumulate):
+    off = 0
+    for i, (k, w) in enumerate(_emb_tables(G)):
+        ops.embed_scatter(G[k], dout[:, off:off + w], labels[:, i:i + 1], accumulate)
+        off += w
+
+
 class Net:
     """Device-side parameters (arena views), gradients and buffers of one network."""
 
@@ -291,7 +316,7 @@ class GenPass:
         dec_in = self.dec_in[:b]
         ops.axpby(dec_in[:, :L], 1.0, self.z[self.nb][:b])
         if labels is not None:
-            ops.embed_gather(dec_in[:, L:], P["embeddings.0.weight"], labels)
+            _embed_gather(ops, dec_in[:, L:], P, labels)
         else:
             dec_in[:, L:].zero_()
         a = dec_in
@@ -344,7 +369,7 @@ class GenPass:
                                 self.dec_stats[li], a_prev, f"decoder.{3 * li}", f"decoder.{3 * li + 1}", d_prev)
         ddi = self.d_dec_in[:b]
         if self.labels is not None:
-            ops.embed_scatter(G["embeddings.0.weight"], ddi[:, L:], self.labels, True)
+            _embed_scatter(ops, G, ddi[:, L:], self.labels, True)
         cur = 0
         ops.axpby(self.dz[cur][:b], 1.0, ddi[:, :L])
         dz = self.dz[cur][:b].view(t, self.D)
@@ -439,7 +464,7 @@ class DiscPass:
         W1 = P["model.0.weight"]
         emb = self.emb[:b]
         if labels is not None:
-            ops.embed_gather(emb, P["embeddings.0.weight"], labels)
+            _embed_gather(ops, emb, P, labels)
         else:
             emb.zero_()
         h0 = self.h0[:b]
@@ -501,7 +526,7 @@ class DiscPass:
             ops.gemm(gW1[:, Gd:], dh0, self.emb[:b], True, False, accumulate=True)
             if self.labels is not None:
                 ops.gemm(self.demb[:b], dh0, W1[:, Gd:], False, False)
-                ops.embed_scatter(G["embeddings.0.weight"], self.demb[:b], self.labels, True)
+                _embed_scatter(ops, G, self.demb[:b], self.labels, True)
         if dx_out is not None:
             ops.gemm(dx_out, dh0, W1[:, :Gd], False, False, accumulate=True)
 
@@ -541,7 +566,7 @@ class DiscPass:
         ops.gemm(gW1[:, Gd:], vh0, self.emb[:b], True, False, accumulate=True)
         if self.labels is not None:
             ops.gemm(self.demb[:b], vh0, W1[:, Gd:], False, False)
-            ops.embed_scatter(G["embeddings.0.weight"], self.demb[:b], self.labels, True)
+            _embed_scatter(ops, G, self.demb[:b], self.labels, True)
 
 
 class CriticStack:
@@ -566,7 +591,7 @@ class CriticStack:
         self.xe = Z(nx * B, _pad4(self.W))
         self.x = self.xe[:, :in_dim]
         self.emb = self.xe[:, in_dim:self.W]
-        self.lab = ops.to_device(torch.zeros(nx * B, 1, dtype=torch.int64))
+        self.lab = ops.to_device(torch.zeros(nx * B, getattr(engine, "n_cov", 1), dtype=torch.int64))
         self.h0, self.a1, self.pm1 = Z(S * B, 1024), Z(S * B, 1024), Z(S * B, 1024)
         self.stats = (Z(S, 1024), Z(S, 1024))
         self.a2, self.pm2 = Z(S * B, 512), Z(S * B, 512)
@@ -606,7 +631,7 @@ class CriticStack:
         W1 = P["model.0.weight"]
         x, emb = self.x[:Rx], self.emb[:Rx]
         if self.have_labels:
-            ops.embed_gather(emb, P["embeddings.0.weight"], self.lab[:Rx])
+            _embed_gather(ops, emb, P, self.lab[:Rx])
         else:
             emb.zero_()
         h0 = self.h0[:R]
@@ -653,7 +678,7 @@ class CriticStack:
         ops.gemm(gW1, dh0, self.xe[:R, :self.W], True, False, accumulate=True)
         if self.have_labels:
             ops.gemm(self.demb[:R], dh0, W1[:, Gd:], False, False)
-            ops.embed_scatter(G["embeddings.0.weight"], self.demb[:R], self.lab[:R], True)
+            _embed_scatter(ops, G, self.demb[:R], self.lab[:R], True)
 
     def backward_input(self, b, coef, idx, scale, dfeat, dx_out):
         """Generator step (nx = nseg - 1): gradient w.r.t. the first input batch of
@@ -718,7 +743,7 @@ class CriticStack:
         ops.gemm(gW1, vh0, xe, True, False, accumulate=True)
         if self.have_labels:
             ops.gemm(self.demb2[:b], vh0, W1[:, Gd:], False, False)
-            ops.embed_scatter(G["embeddings.0.weight"], self.demb2[:b], self.lab[sl], False)
+            _embed_scatter(ops, G, self.demb2[:b], self.lab[sl], False)
 
 
 class EngineBase:
@@ -871,8 +896,8 @@ class StepEngine(EngineBase):
         gm = nets["g_m2h"]["encoder.0.weight"].shape[1]
         gh = nets["g_h2m"]["encoder.0.weight"].shape[1]
         self.g_mouse, self.g_human = gm, gh
-        self.emb_dim = nets["g_m2h"]["embeddings.0.weight"].shape[1]
-        assert not any(k.startswith("embeddings.1.") for k in nets["g_m2h"]), "one categorical covariate is supported"
+        self.emb_dim = sum(w for _, w in _emb_tables(nets["g_m2h"]))
+        self.n_cov = len(_emb_tables(nets["g_m2h"]))
         split = {n: split_state(sd) for n, sd in nets.items()}
         order = {n: _arena_order(list(split[n][0].keys())) for n in nets}
         self.arena_g = Arena(ops, [((n, k), tuple(split[n][0][k].shape)) for n in ("g_m2h", "g_h2m") for k in order[n]])

@@ -242,6 +242,48 @@ def test_modules_against_oracle_edge_configurations(sparse, with_labels, gm, gh,
             assert rel(params[k].grad, P[k].grad, floor) <= 1.0, (k, rel(params[k].grad, P[k].grad, floor))
 
 
+def test_modules_with_two_covariates_against_oracle():
+    """vocab_sizes with two entries: two embedding tables concatenated into the decoder / critic input
+    (GAN_functions.py:85-86,:135,:160-161,:182), gradients for both tables, and the gradient penalty."""
+    from cycle_gan_rna_amd import GAN_functions as F
+    from cycle_gan_rna_amd.noise import HostReplayNoise
+    from oracle import cyclegan_oracle as O
+    cfg = O.default_config(hidden_dims=[96, 64, 32], preprocess_type="log_normalized")
+    gm, gh, B = 44, 52, 12
+    torch.manual_seed(5)
+    gen = F.GeneExpressionGenerator(gm, gh, [12, 5], cfg)
+    dis = F.GeneExpressionDiscriminator(gh, [12, 5], cfg)
+    dev = torch.device("cuda:0")
+    xm, _ = O.synthetic_expression(B, gm, 12, seed=1)
+    xh, _ = O.synthetic_expression(B, gh, 12, seed=2)
+    g = torch.Generator().manual_seed(3)
+    lab = torch.stack([O.balanced_labels(B, 12, 2), torch.randint(0, 5, (B,), generator=g)], 1)
+    Pg, Pd = _oracle_state(gen), _oracle_state(dis)
+    for P in (Pg, Pd):
+        for k in O.param_names(P):
+            P[k].requires_grad_(True)
+    torch.manual_seed(3)
+    nz = O.GlobalRngNoise()
+    out, mu, lv = O.generator_forward(Pg, xm, lab, cfg, nz, train=True)
+    val, feat = O.discriminator_forward(Pd, out, lab, nz)
+    gp = O.gradient_penalty(Pd, xh, out.detach(), lab, nz)
+    (val.mean() + 0.1 * feat.pow(2).mean() + 0.01 * (mu * lv).mean() + 2.0 * gp).backward()
+    torch.manual_seed(3)
+    src = HostReplayNoise(dev)
+    gen._noise_source = src
+    dis._noise_source = src
+    o2, mu2, lv2 = gen(xm.to(dev), lab.to(dev))
+    v2, f2 = dis(o2, lab.to(dev), return_features=True)
+    gp2 = F.compute_gradient_penalty(dis, xh.to(dev), o2.detach(), dev, lab.to(dev))
+    (v2.mean() + 0.1 * f2.pow(2).mean() + 0.01 * (mu2 * lv2).mean() + 2.0 * gp2).backward()
+    assert rel(o2, out) <= 2e-4 and rel(v2, val) <= 2e-4 and rel(gp2, gp) <= 2e-4
+    for mod, P in ((gen, Pg), (dis, Pd)):
+        params = dict(mod.named_parameters())
+        floor = 1e-3 * max(float(P[k].grad.abs().max()) for k in O.param_names(P) if P[k].grad is not None)
+        for k in ("embeddings.0.weight", "embeddings.1.weight", "decoder.0.weight" if mod is gen else "model.0.weight"):
+            assert rel(params[k].grad, P[k].grad, floor) <= 1.0, (k, rel(params[k].grad, P[k].grad, floor))
+
+
 @pytest.mark.parametrize("E,heads", [(16, 4), (8, 2), (32, 8), (16, 16), (4, 1)])
 def test_standalone_blocks_match_torch_modules(E, heads):
     """ResidualBlock and GeneSelfAttention used on their own (eval mode: no dropout) against the

@@ -133,3 +133,38 @@ def test_curriculum_options_equal_autograd_in_float64():
                 continue
             tol = 1e-4 if k.endswith("running_mean") else 5e-5
             assert rel(v, tr.nets[n][k]) <= tol, (n, k, rel(v, tr.nets[n][k]))
+
+
+def test_two_categorical_covariates_equal_autograd_in_float64():
+    """One nn.Embedding per covariate, concatenated (GAN_functions.py:85,:135,:160,:182); the centroid lookup of
+    the cell-type term reads the first covariate."""
+    from cycle_gan_rna_amd.engine import StepEngine
+    from cycle_gan_rna_amd.noise import HostReplayNoise
+    from oracle import init_params
+    dtype = torch.float64
+    cfg = small_cfg(preprocess_type="log_normalized", nb_critic=2)
+    nets = init_params.build_nets(40, 36, [12, 5], cfg, 3)
+    nets = {n: {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd.items()} for n, sd in nets.items()}
+    assert nets["d_m"]["model.0.weight"].shape[1] == 40 + 12 + 5
+    B = 12
+    xm, _ = O.synthetic_expression(B, 40, 12, seed=100)
+    xh, _ = O.synthetic_expression(B, 36, 12, seed=101)
+    xm, xh = xm.to(dtype), xh.to(dtype)
+    g = torch.Generator().manual_seed(7)
+    lm = torch.stack([O.balanced_labels(B, 12, 102), torch.randint(0, 5, (B,), generator=g)], 1)
+    lh = torch.stack([O.balanced_labels(B, 12, 103), torch.randint(0, 5, (B,), generator=g)], 1)
+    cm, ch = O.centroid_table(xm, lm[:, 0], 12), O.centroid_table(xh, lh[:, 0], 12)
+    tr = O.OracleTrainer(nets, cfg, cm, ch)
+    torch.manual_seed(11)
+    exp = [tr.iteration(i, xm, xh, lm, lh) for i in range(3)]
+    eng = StepEngine(nets, cfg, cm, ch, CpuOps(dtype), B)
+    torch.manual_seed(11)
+    got = [eng.iteration(i, xm, xh, lm, lh, HostReplayNoise("cpu", dtype)) for i in range(3)]
+    for e, g_ in zip(exp, got):
+        if g_:
+            for k in LOSS_KEYS:
+                assert rel(g_[k], e[k]) <= 5e-7, (k, g_[k], e[k])
+    for n in ("g_m2h", "g_h2m", "d_m", "d_h"):
+        sd = eng.state_dict(n)
+        for k in ("embeddings.0.weight", "embeddings.1.weight"):
+            assert rel(sd[k], tr.nets[n][k]) <= 5e-5, (n, k, rel(sd[k], tr.nets[n][k]))
