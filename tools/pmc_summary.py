@@ -22,7 +22,7 @@ def family(name):
 
 
 def mean_per_family(d):
-    f = glob.glob(f"{d}/*/*_counter_collection.csv")[0]
+    f = glob.glob(f"{d}/**/*counter_collection.csv", recursive=True)[0]
     agg = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
         a = agg[family(r["Kernel_Name"])]
