@@ -1,4 +1,4 @@
-# Final-state measurements of a round, on the GPU box: default bench line, rocprofv3 kernel statistics of the step on
+# Measurements of the current build, on the GPU box: default bench line, rocprofv3 kernel statistics of the step on
 # one stream (float32 and bf16 mode), and the two PMC passes for HBM traffic.  Writes under gpurun_out/.
 set -e -o pipefail
 R=$GRAFT_REPO_ROOT
