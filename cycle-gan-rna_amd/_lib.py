@@ -21,8 +21,8 @@ Z = C.c_size_t
 
 
 class GlossDesc(C.Structure):
-    _fields_ = [("n_terms", C.c_int * 5), ("slot", (C.c_int * 4) * 5), ("weight", (C.c_double * 4) * 5),
-                ("lambda_", C.c_double * 5), ("ema_alpha", C.c_double), ("weights", C.c_void_p)]
+    _fields_ = [("n_terms", C.c_int * 6), ("slot", (C.c_int * 4) * 6), ("weight", (C.c_double * 4) * 6),
+                ("lambda_", C.c_double * 6), ("ema_alpha", C.c_double), ("weights", C.c_void_p)]
 
 
 SIGNATURES = {

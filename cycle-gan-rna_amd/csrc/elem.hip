@@ -354,8 +354,8 @@ __device__ double sum_slot(const float* parts, const int* nparts, int slot) {
 
 __global__ void __launch_bounds__(64) gloss_finalize_kernel(double* ema, double* losses, float* coef, const float* parts,
                                                             const int* nparts, cg_gloss_desc d) {
-  double L[5];
-  for (int k = 0; k < 5; ++k) {
+  double L[6];
+  for (int k = 0; k < 6; ++k) {
     // each term is rounded to float32 like the tensor the reference calls .item() on
     float acc = 0.f;
     for (int j = 0; j < d.n_terms[k]; ++j) acc = acc + (float)(d.weight[k][j] * sum_slot(parts, nparts, d.slot[k][j]));
@@ -371,7 +371,9 @@ __global__ void __launch_bounds__(64) gloss_finalize_kernel(double* ema, double*
       losses[k] = L[k];
       losses[6 + k] = 1.0;
     }
-    losses[5] = g;
+    coef[5] = (float)d.lambda[5];
+    losses[11] = L[5];
+    losses[5] = g + d.lambda[5] * L[5];
     return;
   }
   const double a = d.ema_alpha;
@@ -390,7 +392,10 @@ __global__ void __launch_bounds__(64) gloss_finalize_kernel(double* ema, double*
     losses[k] = L[k];
     losses[6 + k] = sc[k];
   }
-  losses[5] = g;
+  // sixth term (identity mapping, no counterpart in GAN_functions.py): fixed weight, outside the re-scaling
+  coef[5] = (float)d.lambda[5];
+  losses[11] = L[5];
+  losses[5] = g + d.lambda[5] * L[5];
 }
 
 __global__ void __launch_bounds__(64) sum_parts_kernel(double* totals, const float* parts, const int* nparts,
@@ -609,7 +614,7 @@ extern "C" int cg_fm_bwd(float* dF, int ldd, const float* mean_fake, const float
 extern "C" int cg_gloss_finalize(double* ema_state, double* losses_out, float* coef_out, const float* parts,
                                  const int* nparts, const cg_gloss_desc* desc, void* stream) {
   if (!ema_state || !losses_out || !coef_out || !parts || !nparts || !desc) return CG_ERR_BAD_ARG;
-  for (int k = 0; k < 5; ++k)
+  for (int k = 0; k < 6; ++k)
     if (desc->n_terms[k] < 0 || desc->n_terms[k] > 4) return CG_ERR_BAD_ARG;
   hipLaunchKernelGGL(gloss_finalize_kernel, dim3(1), dim3(64), 0, ST, ema_state, losses_out, coef_out, parts, nparts,
                      *desc);

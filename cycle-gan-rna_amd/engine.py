@@ -36,7 +36,9 @@ BUFFER_SUFFIXES = ("running_mean", "running_var", "num_batches_tracked")
 
 # reduction slots
 (S_DM_REAL, S_DM_FAKE, S_DM_GP, S_DH_REAL, S_DH_FAKE, S_DH_GP,
- S_ADV_H, S_ADV_M, S_CYC_M, S_CYC_H, S_CT_H, S_CT_M, S_FM_H, S_FM_M, S_KL_H, S_KL_M, N_SLOTS) = range(17)
+ S_ADV_H, S_ADV_M, S_CYC_M, S_CYC_H, S_CT_H, S_CT_M, S_FM_H, S_FM_M, S_KL_H, S_KL_M, S_IDT_M, S_IDT_H,
+ N_SLOTS) = range(19)
+N_GSLOTS = 12           # slots of the generator step (S_ADV_H ... S_IDT_H)
 MAX_PARTS = 1024
 PIN_SLOTS = 64          # staging slots for the {lr, step} uploads of optimizer steps in flight
 
@@ -939,8 +941,8 @@ class StepEngine(EngineBase):
         self.d_feat = Z(B, 256)
         self.one = ops.to_device(torch.ones(1))
         self.ema = Z(5, dtype=torch.float64)                 # :283-287
-        self.gloss = Z(11, dtype=torch.float64)
-        self.coef = Z(5)
+        self.gloss = Z(12, dtype=torch.float64)
+        self.coef = Z(6)
         self.d_tot = Z(6, dtype=torch.float64)
         self.d_slots = ops.to_device(torch.arange(6, dtype=torch.int32))
         self.d_scales = Z(6, dtype=torch.float64)
@@ -950,9 +952,18 @@ class StepEngine(EngineBase):
         self.d_feat2 = Z(B, 256)
         from .ddp import GradSync
         self.sync = GradSync(ops.device)
-        self.g_tot = Z(10, dtype=torch.float64)
-        self.g_slots = ops.to_device(torch.arange(S_ADV_H, S_ADV_H + 10, dtype=torch.int32))
-        self.g_ones = ops.to_device(torch.ones(10, dtype=torch.float64))
+        self.g_tot = Z(N_GSLOTS, dtype=torch.float64)
+        self.g_slots = ops.to_device(torch.arange(S_ADV_H, S_ADV_H + N_GSLOTS, dtype=torch.int32))
+        self.g_ones = ops.to_device(torch.ones(N_GSLOTS, dtype=torch.float64))
+        # identity loss: L1(g_m2h(human), human) + L1(g_h2m(mouse), mouse), the identity-mapping term of CycleGAN.
+        # GAN_functions.py has no such term; it is an extension that config key 'lambda_identity' (> 0) switches on,
+        # with a fixed weight outside the dynamic re-scaling.  Needs the two species to share one gene space.
+        self.lambda_identity = float(cfg.get("lambda_identity", 0.0))
+        self.gen_i = None
+        if self.lambda_identity > 0:
+            assert gm == gh, "the identity loss needs the same genes on both sides"
+            self.gen_i = {"g_m2h": GenPass(self, N["g_m2h"], gm, gh, B), "g_h2m": GenPass(self, N["g_h2m"], gh, gm, B)}
+            self.d_idt = {"human": Z(B, gh), "mouse": Z(B, gm)}
 
     @staticmethod
     def _critic_noise(noise, b, nseg, draw_order=None, alpha_before=None, first=None):
@@ -1151,6 +1162,13 @@ class StepEngine(EngineBase):
                 ops.reduce_poisson(red, slot, o[key], target)
             else:
                 ops.reduce_l1(red, slot, o[key], target)
+            if self.gen_i:      # identity pass of the same network, in the same branch (its running statistics see
+                if key == "rm":                                     # one order): g_h2m(mouse) / g_m2h(human)
+                    o["im"] = self.gen_i["g_h2m"].forward(mouse, mouse_cat, noise)
+                    ops.reduce_l1(red, S_IDT_M, o["im"], mouse)
+                else:
+                    o["ih"] = self.gen_i["g_m2h"].forward(human, human_cat, noise)
+                    ops.reduce_l1(red, S_IDT_H, o["ih"], human)
 
         def critics(name, fake, real, lab, cents, src_lab, s_adv, s_ct, m_real, m_fake, s_fm, gen_first, s_kl):
             # segments: adversarial call on the generated batch (:347) | feature call on it (:368,:371) | feature
@@ -1190,8 +1208,8 @@ class StepEngine(EngineBase):
         Rm, Rh = self.gen_b["g_h2m"], self.gen_b["g_m2h"]
         L = cfg["latent_dim"]
         if self.sync.enabled:
-            red[0][S_ADV_H:S_ADV_H + 10, 0] = self.g_tot.to(red[0].dtype)
-            red[1][S_ADV_H:S_ADV_H + 10] = 1
+            red[0][S_ADV_H:S_ADV_H + N_GSLOTS, 0] = self.g_tot.to(red[0].dtype)
+            red[1][S_ADV_H:S_ADV_H + N_GSLOTS] = 1
         bl = b
         b = b * self.sync.world          # normalisation of the global-batch losses
         desc = dict(
@@ -1199,11 +1217,12 @@ class StepEngine(EngineBase):
                    [(S_CYC_M, 1.0 / (b * gm)), (S_CYC_H, 1.0 / (b * gh))],
                    [(S_CT_H, 1.0 / (b * gh)), (S_CT_M, 1.0 / (b * gm))],
                    [(S_FM_H, 0.5 / 256 / self.sync.world), (S_FM_M, 0.5 / 256 / self.sync.world)],
-                   [(S_KL_H, -0.5 / (b * L)), (S_KL_M, -0.5 / (b * L))]],
+                   [(S_KL_H, -0.5 / (b * L)), (S_KL_M, -0.5 / (b * L))],
+                   [(S_IDT_H, 1.0 / (b * gh)), (S_IDT_M, 1.0 / (b * gm))] if self.gen_i else []],
             ema_alpha=0.3)
         b = bl
         desc["lambda"] = [float(cfg["lambda_adv"]), float(cfg["lambda_cycle"]), float(cfg["lambda_celltype"]),
-                          float(cfg["lambda_fm"]), float(cfg["lambda_kl"])]
+                          float(cfg["lambda_fm"]), float(cfg["lambda_kl"]), self.lambda_identity]
         desc["weights"] = self.ext_weights
         ops.gloss_finalize(self.ema, self.gloss, self.coef, red, desc)     # :380-406
         coef = self.coef
@@ -1222,6 +1241,12 @@ class StepEngine(EngineBase):
             else:
                 ops.l1_bwd(drec, recov, target, coef, 1, 1.0 / (b * tdim))
             R.backward(drec, need_dx=True, dx_out=dx)
+            if self.gen_i:      # the identity pass of the same network (its gradients go to the same tensors)
+                side = "mouse" if R is Rm else "human"
+                I = self.gen_i["g_h2m" if R is Rm else "g_m2h"]
+                di = self.d_idt[side][:b]
+                ops.l1_bwd(di, o["im" if R is Rm else "ih"], target, coef, 5, 1.0 / (b * tdim))
+                I.backward(di)
         dch, dcm = self.d_cyc["human"][:b], self.d_cyc["mouse"][:b]
         self._many(lambda: crit(dfh, fake_human, self.human_centroids, mouse_cat, gh, self.gstack["d_h"], "h_fake",
                                 "h_real", self.d_feat[:b]),
@@ -1265,7 +1290,7 @@ class StepEngine(EngineBase):
         v = self.var_out.cpu()
         f32 = lambda x: float(torch.tensor(float(x), dtype=torch.float32))  # noqa: E731
         return dict(g_adv=float(t[0]), cycle_loss=float(t[1]), celltype_loss=float(t[2]), fm_loss=float(t[3]),
-                    kl_loss=float(t[4]), g_loss=f32(t[5]),
+                    kl_loss=float(t[4]), g_loss=f32(t[5]), identity_loss=float(t[11]),
                     scales=dict(adv=float(t[6]), cycle=float(t[7]), celltype=float(t[8]), fm=float(t[9]), kl=float(t[10])),
                     fake_human_var=float(v[0]), fake_mouse_var=float(v[1]))
 

@@ -370,7 +370,7 @@ class HipOps:
     def gloss_finalize(self, ema, losses, coef, red, desc):
         parts, nparts = red
         d = _lib.GlossDesc()
-        for k in range(5):
+        for k in range(len(desc["terms"])):          # five terms, or six with the identity term
             terms = desc["terms"][k]
             d.n_terms[k] = len(terms)
             for j, (slot, w) in enumerate(terms):
@@ -381,7 +381,7 @@ class HipOps:
         w = desc.get("weights")
         assert w is None or (w.dtype == torch.float32 and w.numel() == 5 and w.is_contiguous())
         d.weights = _ptr(w)
-        assert ema.dtype == torch.float64 and losses.dtype == torch.float64 and losses.numel() >= 11
+        assert ema.dtype == torch.float64 and losses.dtype == torch.float64 and losses.numel() >= 12 and coef.numel() >= 6
         st = self.lib.cg_gloss_finalize(_ptr(ema), _ptr(losses), _ptr(coef), _ptr(parts), _ptr(nparts), C.byref(d),
                                         self._stream())
         _lib.check(st, "cg_gloss_finalize")

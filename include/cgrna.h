@@ -265,14 +265,17 @@ int cg_fm_bwd(float* dF, int ldd, const float* mean_fake, const float* mean_real
  * nparts[slot]; slot meaning and normalisation are given by the caller in
  * `desc` (see cgrna_amd/engine.py).  Updates the five moving averages
  * (alpha = 0.3), computes the scales, and writes
- *   losses_out: 11 doubles - g_adv, g_cycle, g_celltype, g_fm, kl, g_loss, then the five scales
- *   coef_out:   5 floats - lambda_i*scale_i for the backward kernels
+ *   losses_out: 12 doubles - g_adv, g_cycle, g_celltype, g_fm, kl, g_loss, the five scales, the sixth term
+ *   coef_out:   6 floats - lambda_i*scale_i for the backward kernels (the sixth: lambda_6)
+ * A sixth term with a fixed weight, outside the moving averages and the re-scaling, is an extension: the identity
+ * loss of CycleGAN, which GAN_functions.py does not have (n_terms[5] = 0 and lambda[5] = 0 give the reference's
+ * g_loss).
  */
 typedef struct {
-  int n_terms[5];        /* number of (slot, weight) pairs per loss: adv, cycle, celltype, fm, kl */
-  int slot[5][4];
-  double weight[5][4];   /* loss_k = sum_j weight[k][j] * total(slot[k][j]) */
-  double lambda[5];
+  int n_terms[6];        /* number of (slot, weight) pairs per loss: adv, cycle, celltype, fm, kl, identity */
+  int slot[6][4];
+  double weight[6][4];   /* loss_k = sum_j weight[k][j] * total(slot[k][j]) */
+  double lambda[6];
   double ema_alpha;
   const float* weights;  /* NULL, or 5 device floats used as coef_out as they are: no moving averages and no
                             re-scaling (the per-epoch curriculum weights of GAN_optimize_optuna.ipynb cell-1,

@@ -412,7 +412,15 @@ class OracleTrainer:
         fake_mouse, mu_m, lv_m = self.G("g_h2m", human, human_cat)
         g_adv = -self.D("d_h", fake_human, human_cat)[0].mean() - self.D("d_m", fake_mouse, mouse_cat)[0].mean()
         recov_mouse, _, _ = self.G("g_h2m", fake_human, human_cat)
+        lam_id = float(cfg.get("lambda_identity", 0.0))
+        g_identity = torch.zeros((), dtype=mouse.dtype)
+        if lam_id > 0:      # identity-mapping term of CycleGAN: an extension, GAN_functions.py has none
+            idt_mouse, _, _ = self.G("g_h2m", mouse, mouse_cat)
+            g_identity = g_identity + (idt_mouse - mouse).abs().mean()
         recov_human, _, _ = self.G("g_m2h", fake_mouse, mouse_cat)
+        if lam_id > 0:
+            idt_human, _, _ = self.G("g_m2h", human, human_cat)
+            g_identity = g_identity + (idt_human - human).abs().mean()
         if self.cycle_poisson:
             g_cycle = poisson_loss(recov_mouse, mouse) + poisson_loss(recov_human, human)
         else:
@@ -433,7 +441,7 @@ class OracleTrainer:
 
         if self.ext_weights is not None:
             w = self.ext_weights
-            g_loss = w[0] * g_adv + w[1] * g_cycle + w[2] * g_celltype + w[3] * g_fm + w[4] * kl
+            g_loss = w[0] * g_adv + w[1] * g_cycle + w[2] * g_celltype + w[3] * g_fm + w[4] * kl + lam_id * g_identity
             g_loss.backward()
             self.opt_g.step()
             return dict(g_loss=g_loss.item(), g_adv=g_adv.item(), cycle_loss=g_cycle.item(),
@@ -456,10 +464,13 @@ class OracleTrainer:
         g_loss = (cfg["lambda_adv"] * s["adv"] * g_adv + cfg["lambda_cycle"] * s["cycle"] * g_cycle +
                   cfg["lambda_celltype"] * s["celltype"] * g_celltype + cfg["lambda_fm"] * s["fm"] * g_fm +
                   cfg["lambda_kl"] * s["kl"] * kl)               # :402-406
+        if lam_id > 0:
+            g_loss = g_loss + lam_id * g_identity
         g_loss.backward()
         self.opt_g.step()
         return dict(g_loss=g_loss.item(), g_adv=g_adv.item(), cycle_loss=g_cycle.item(),
                     celltype_loss=g_celltype.item(), fm_loss=g_fm.item(), kl_loss=kl.item(),
+                    identity_loss=g_identity.item(),
                     fake_human_var=torch.var(fake_human.detach(), dim=0).mean().item(),   # :418-419
                     fake_mouse_var=torch.var(fake_mouse.detach(), dim=0).mean().item(),
                     scales=dict(s), ema=dict(e),

@@ -323,9 +323,9 @@ class CpuOps:
 
     def gloss_finalize(self, ema, losses, coef, red, desc):
         L = []
-        for k in range(5):
+        for k in range(6):
             acc = torch.zeros((), dtype=torch.float32)
-            for slot, w in desc["terms"][k]:
+            for slot, w in (desc["terms"][k] if k < len(desc["terms"]) else []):
                 acc = acc + torch.tensor(w * self._slot_total(red, slot), dtype=torch.float32)
             L.append(float(acc))
         if desc.get("weights") is not None:
@@ -336,7 +336,10 @@ class CpuOps:
                 g += c * L[k]
                 losses[k] = L[k]
                 losses[6 + k] = 1.0
-            losses[5] = g
+            lam6 = desc["lambda"][5] if len(desc["lambda"]) > 5 else 0.0
+            coef[5] = lam6
+            losses[11] = L[5]
+            losses[5] = g + lam6 * L[5]
             return
         a = desc["ema_alpha"]
         for k in range(5):
@@ -351,7 +354,10 @@ class CpuOps:
             g += c * L[k]
             losses[k] = L[k]
             losses[6 + k] = sc[k]
-        losses[5] = g
+        lam6 = desc["lambda"][5] if len(desc["lambda"]) > 5 else 0.0
+        coef[5] = lam6
+        losses[11] = L[5]
+        losses[5] = g + lam6 * L[5]
 
     def sum_parts(self, totals, red, slots, scales):
         for i in range(slots.numel()):

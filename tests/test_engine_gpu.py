@@ -135,6 +135,39 @@ def test_other_latent_geometries_match_oracle(ops, latent_dim, heads, blocks, hi
     check_updates(nets, tr, eng, 3e-1)
 
 
+def test_identity_loss_extension_matches_oracle(ops):
+    """'lambda_identity' > 0 (an extension, off in the reference's config): two more generator passes per generator
+    step, a sixth loss term with a fixed weight; HIP engine against the oracle, and HIP-graph replay with side
+    streams against eager launches."""
+    from cycle_gan_rna_amd.engine import StepEngine
+    from cycle_gan_rna_amd.noise import DeviceNoise
+    cfg = small_cfg(preprocess_type="log_normalized", nb_critic=2, lambda_identity=0.7)
+    nets, tr, eng, exp, got = run_both(ops, cfg, 48, 48, 16, iters=3)
+    for i, (e, g) in enumerate(zip(exp, got)):
+        if not g:
+            continue
+        for k in LOSS_KEYS + ("identity_loss",):
+            assert rel(g[k], e[k], FLOOR.get(k, 0.0)) <= (1e-4 if i == 0 else 5e-3), (i, k, g[k], e[k])
+    assert exp[0]["identity_loss"] > 0
+    check_updates(nets, tr, eng, 3e-1)
+    nets, xm, xh, lm, lh = make_problem(48, 48, 16, cfg)
+    cm, ch = O.centroid_table(xm, lm, 12), O.centroid_table(xh, lh, 12)
+    dx = [t.cuda() for t in (xm, xh, lm[:, None], lh[:, None])]
+    finals = []
+    for fast in (False, True):
+        e2 = StepEngine(nets, cfg, cm, ch, ops, 16)
+        if fast:
+            e2.enable_concurrency()
+            e2.enable_graphs()
+        noise = DeviceNoise(ops.device, seed=7, default_generator=True)
+        for i in range(5):
+            noise.begin_step()
+            out = e2.iteration(i, *dx, noise)
+        torch.cuda.synchronize()
+        finals.append((e2.arena_g.p.clone(), out["identity_loss"]))
+    assert torch.equal(finals[0][0], finals[1][0]) and finals[0][1] == finals[1][1]
+
+
 def test_default_hidden_dims_one_iteration(ops):
     """Default architecture (2048/1024/512 hidden) at a modest gene count."""
     cfg = O.default_config(preprocess_type="log_normalized", nb_critic=1)

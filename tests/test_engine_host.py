@@ -168,3 +168,25 @@ def test_two_categorical_covariates_equal_autograd_in_float64():
         sd = eng.state_dict(n)
         for k in ("embeddings.0.weight", "embeddings.1.weight"):
             assert rel(sd[k], tr.nets[n][k]) <= 5e-5, (n, k, rel(sd[k], tr.nets[n][k]))
+
+
+def test_identity_loss_extension_equals_autograd_in_float64():
+    """config key 'lambda_identity' > 0 adds L1(g_m2h(human), human) + L1(g_h2m(mouse), mouse) with a fixed weight (the
+    identity term of CycleGAN; GAN_functions.py has none, so the key is absent from its config and the term is off
+    by default).  Parity unpinned; the explicit backward is checked against autograd."""
+    nets, tr, eng, exp, got = run(torch.float64, "log_normalized", 40, 40, 12, iters=3, lambda_identity=0.7)
+    assert exp[0]["identity_loss"] > 0
+    for e, g in zip(exp, got):
+        if g:
+            for k in LOSS_KEYS + ("identity_loss",):
+                assert rel(g[k], e[k]) <= 5e-7, (k, g[k], e[k])
+    for n in ("g_m2h", "g_h2m"):
+        sd = eng.state_dict(n)
+        for k, v in sd.items():
+            if O.is_gauge_param(k, sd):
+                continue
+            tol = 1e-4 if k.endswith("running_mean") else 5e-5
+            assert rel(v, tr.nets[n][k]) <= tol, (n, k, rel(v, tr.nets[n][k]))
+    # off by default: the metric is there and zero
+    nets, tr, eng, exp, got = run(torch.float64, "log_normalized", 40, 40, 12, iters=1)
+    assert got[0]["identity_loss"] == 0.0

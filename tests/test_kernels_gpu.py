@@ -400,11 +400,11 @@ def test_reductions_and_loss_bookkeeping(ops):
     close(tot, etot, 1e-5, "sum_parts")     # float32 partial sums inside each block
     # loss bookkeeping: two consecutive calls (moving averages carry over)
     desc = dict(terms=[[(0, -1.0 / M), (5, -1.0 / M)], [(1, 1.0 / (M * N))], [(2, 1.0 / (M * N))], [(4, 0.5 / N)],
-                       [(3, -0.5 / (M * 512))]], ema_alpha=0.3)
-    desc["lambda"] = [1.0, 1.0, 0.2, 0.3, 0.1]
+                       [(3, -0.5 / (M * 512))], [(1, 0.5 / (M * N)), (0, 0.25 / (M * N))]], ema_alpha=0.3)
+    desc["lambda"] = [1.0, 1.0, 0.2, 0.3, 0.1, 0.7]      # the sixth term: fixed weight, outside the re-scaling
     ema, eema = torch.zeros(5, dtype=torch.float64).cuda(), torch.zeros(5, dtype=torch.float64)
-    losses, elosses = torch.zeros(11, dtype=torch.float64).cuda(), torch.zeros(11, dtype=torch.float64)
-    coef, ecoef = torch.zeros(5).cuda(), torch.zeros(5)
+    losses, elosses = torch.zeros(12, dtype=torch.float64).cuda(), torch.zeros(12, dtype=torch.float64)
+    coef, ecoef = torch.zeros(6).cuda(), torch.zeros(6)
     for _ in range(2):
         ops.gloss_finalize(ema, losses, coef, red, desc)
         c64.gloss_finalize(eema, elosses, ecoef, ered, desc)
@@ -478,9 +478,9 @@ def test_poisson_cycle_loss_weights_and_plain_adam(ops):
     w = torch.tensor([0.0, 7.5, 0.25, 0.0, 0.01])
     desc["weights"] = dev(w)
     ema = torch.full((5,), 3.0, dtype=torch.float64).cuda()
-    losses, coef = torch.zeros(11, dtype=torch.float64).cuda(), torch.zeros(5).cuda()
+    losses, coef = torch.zeros(12, dtype=torch.float64).cuda(), torch.zeros(6).cuda()
     ops.gloss_finalize(ema, losses, coef, red, desc)
-    assert torch.equal(coef.cpu(), w) and torch.equal(ema.cpu(), torch.full((5,), 3.0, dtype=torch.float64))
+    assert torch.equal(coef.cpu()[:5], w) and torch.equal(ema.cpu(), torch.full((5,), 3.0, dtype=torch.float64))
     L = losses.cpu()
     assert abs(float(L[5]) - float((w.double() * L[:5]).sum())) <= 1e-9 * abs(float(L[5])) + 1e-12
     # plain Adam
