@@ -599,6 +599,9 @@ def train_enhanced_cycle_gan(g_m2h, g_h2m, d_m, d_h, mouse_adata, human_adata,
     key_map = (('g_loss', 'g_loss'), ('d_m_loss', 'd_m_loss'), ('d_h_loss', 'd_h_loss'), ('cycle_loss', 'cycle_loss'),
                ('celltype_loss', 'celltype_loss'), ('fm_loss', 'fm_loss'), ('kl_loss', 'kl_loss'),
                ('fake_human_var', 'fake_human_var'), ('fake_mouse_var', 'fake_mouse_var'))
+    if float(config.get('lambda_identity', 0.0)) > 0:          # extension (see StepEngine): reported with the others
+        key_map = key_map + (('identity_loss', 'identity_loss'),)
+        metrics['identity_loss'] = []
     last = {}
     for epoch in epochs:
         acc = {k: [] for k, _ in key_map}
