@@ -155,13 +155,17 @@ def test_train_function_against_reference(tag):
     assert float((got - ref_final["values"].double()).norm() / upd_ref.norm()) <= 0.35
 
 
-def test_train_function_default_mode_replays_graphs():
+@pytest.mark.parametrize("identity", [False, True])
+def test_train_function_default_mode_replays_graphs(identity):
     """Default mode of the drop-in loop (noise drawn in HBM): the step runs as HIP graphs on several streams.  With
-    the same seed, a run that launches every kernel eagerly on one stream gives the same metrics bit for bit."""
+    the same seed, a run that launches every kernel eagerly on one stream gives the same metrics bit for bit.
+    identity: the same with the identity-loss extension switched on (one gene list for both species)."""
     from cycle_gan_rna_amd import GAN_functions as F
     from oracle import cyclegan_oracle as O
     fx = torch.load(os.path.join(GOLD, "function_level.pt"), weights_only=True)["one_iter_epochs"]
     gm, gh, N = fx["g_mouse"], fx["g_human"], fx["N"]
+    if identity:
+        gh = gm
     xm, _ = O.synthetic_expression(N, gm, 12, seed=3)
     xh, _ = O.synthetic_expression(N, gh, 12, seed=4)
     lm, lh = O.balanced_labels(N, 12, 5), O.balanced_labels(N, 12, 6)
@@ -172,6 +176,8 @@ def test_train_function_default_mode_replays_graphs():
     for mode in ("fast", "plain"):
         cfg = dict(fx["cfg"], device="cuda", progress=False, epochs=4, hip_graphs=mode == "fast",
                    concurrent_streams=mode == "fast")
+        if identity:
+            cfg["lambda_identity"] = 0.5
         mods = build_modules(gm, gh, cfg, fx["init_seed"])
         with tempfile.TemporaryDirectory() as tmp:
             os.chdir(tmp)
@@ -184,6 +190,7 @@ def test_train_function_default_mode_replays_graphs():
             finally:
                 os.chdir(cwd)
         assert all(np.isfinite(v).all() for v in metrics.values())
+        assert ("identity_loss" in metrics) == identity and (not identity or min(metrics["identity_loss"]) > 0)
         res[mode] = (metrics, mods[0].state_dict()["encoder.0.weight"].cpu())
     for k in res["fast"][0]:
         assert res["fast"][0][k] == res["plain"][0][k], k
