@@ -776,6 +776,15 @@ extern "C" int cg_gemm(float* C, int ldc, const void* A, int lda, const void* B,
       }
     }
   }
+  if (const char* f = getenv("CGRNA_GEMM_OVERRIDE")) {   // tuning aid: "M,N,K,transA,transB,accumulate,tile,splits" for one shape
+    int m, n, k, ta, tb, ac, t = 0, sp = 1;
+    if (sscanf(f, "%d,%d,%d,%d,%d,%d,%d,%d", &m, &n, &k, &ta, &tb, &ac, &t, &sp) == 8 && m == M && n == N && k == K &&
+        ta == transA && tb == transB && ac == accumulate && t >= 0 && t < 3 && sp >= 1 &&
+        (sp == 1 || (workspace && (size_t)sp * per <= workspace_bytes && nk / sp >= 1))) {
+      best = t;
+      best_splits = sp;
+    }
+  }
   if (const char* f = getenv("CGRNA_GEMM_FORCE")) {   // tuning aid: "tile,splits" with tile 0=128x128 1=128x64 2=64x64
     int t = 0, sp = 1;
     if (sscanf(f, "%d,%d", &t, &sp) == 2 && t >= 0 && t < 3 && sp >= 1 && (sp == 1 || (workspace && (size_t)sp * per <= workspace_bytes))) {
