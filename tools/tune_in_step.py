@@ -5,7 +5,7 @@ operands of a product come from HBM and the choice that wins there can be a diff
 (one stream, every launch bracketed by HIP events, as bench.py's roofline pass does) and, shape by shape, every
 candidate is forced through CGRNA_GEMM_OVERRIDE and timed where it is used.  Prints the table rows of the winners.
 
-    python tools/tune_in_step.py [bf16] > gpurun_out/in_step_f32.csv
+    python tools/tune_in_step.py [bf16] [--thresh=0.97] > gpurun_out/in_step_f32.csv
 """
 import os
 import sys
@@ -19,7 +19,11 @@ from cycle_gan_rna_amd.noise import DeviceNoise  # noqa: E402
 from cycle_gan_rna_amd.ops import HipOps  # noqa: E402
 
 G, B, NB = 5000, 512, 4
-half = len(sys.argv) > 1 and sys.argv[1] == "bf16"
+half = "bf16" in sys.argv[1:]
+THRESH = 0.97          # a candidate must beat the current choice by 3 % (--thresh=0.98 for 2 %), twice
+for _a in sys.argv[1:]:
+    if _a.startswith("--thresh="):
+        THRESH = float(_a.split("=", 1)[1])
 dev = torch.device("cuda", 0)
 cfg = S.default_config(preprocess_type="log_normalized", batch_size=B)
 nets = S.random_networks(G, G, [12], cfg, seed=0)
@@ -70,12 +74,12 @@ for shape in shapes:
             if us < best[0]:
                 best = (us, (t, sp))
     os.environ.pop("CGRNA_GEMM_OVERRIDE", None)
-    if best[1] is not None and best[0] < 0.97 * cur:          # confirm a candidate that looks at least 3 % faster
+    if best[1] is not None and best[0] < THRESH * cur:          # confirm a candidate that looks faster by the threshold
         os.environ["CGRNA_GEMM_OVERRIDE"] = f"{M},{N},{K},{ta},{tb},{acc},{best[1][0]},{best[1][1]}"
         again = measure(3)[shape][0]
         os.environ.pop("CGRNA_GEMM_OVERRIDE", None)
         recheck = measure(3)[shape][0]
-        if again < 0.97 * recheck:
+        if again < THRESH * recheck:
             total_gain += (recheck - again) * n_it
             print(f"{M},{N},{K},{ta},{tb},{acc},{best[1][0]},{best[1][1]},{again:.2f},{recheck:.2f},{n_it:.2f}", flush=True)
             continue
