@@ -5,7 +5,7 @@ operands of a product come from HBM and the choice that wins there can be a diff
 (one stream, every launch bracketed by HIP events, as bench.py's roofline pass does) and, shape by shape, every
 candidate is forced through CGRNA_GEMM_OVERRIDE and timed where it is used.  Prints the table rows of the winners.
 
-    python tools/tune_in_step.py [bf16] [--thresh=0.97] > gpurun_out/in_step_f32.csv
+    python tools/tune_in_step.py [bf16] [--thresh=0.97] [--genes=5000] [--batch=512] > gpurun_out/in_step_f32.csv
 """
 import os
 import sys
@@ -19,6 +19,11 @@ from cycle_gan_rna_amd.noise import DeviceNoise  # noqa: E402
 from cycle_gan_rna_amd.ops import HipOps  # noqa: E402
 
 G, B, NB = 5000, 512, 4
+for _a in sys.argv[1:]:
+    if _a.startswith("--genes="):
+        G = int(_a.split("=", 1)[1])
+    if _a.startswith("--batch="):
+        B = int(_a.split("=", 1)[1])
 half = "bf16" in sys.argv[1:]
 THRESH = 0.97          # a candidate must beat the current choice by 3 % (--thresh=0.98 for 2 %), twice
 for _a in sys.argv[1:]:
