@@ -770,6 +770,13 @@ class EngineBase:
         self.ops.prepare_stream(torch.cuda.current_stream(self.ops.device))
         self.concurrent = True
 
+    def _check_stream_priority(self):
+        """Branches on side streams joined to a caller's stream of raised priority stop making progress on this
+        ROCm build (eagerly now and then, replayed from a graph always), so that combination is refused."""
+        if self.concurrent and getattr(torch.cuda.current_stream(self.ops.device), "priority", 0) != 0:
+            raise RuntimeError("the step's concurrent branches need a current stream of default priority "
+                               "(call the engine from such a stream, or do not enable_concurrency())")
+
     def _many(self, *branches):
         """Run independent branches side by side: the first on the current stream, the others on side streams
         that start from what the current stream has queued so far; then join.  The host calls them in the order
@@ -778,6 +785,7 @@ class EngineBase:
             for fn in branches:
                 fn()
             return
+        self._check_stream_priority()
         main = torch.cuda.current_stream(self.ops.device)
         used = (self.sides if self._lane_sides is None else self._lane_sides)[:len(branches) - 1]
         assert len(used) == len(branches) - 1, "this lane has too few side streams"
@@ -845,6 +853,7 @@ class EngineBase:
         self.use_graphs = True
 
     def _graphed(self, kind, body, tensors, noise):
+        self._check_stream_priority()
         st = self._graphs.setdefault(kind, dict(calls=0, graph=None, static=None, nbt=None))
         if st["static"] is None:
             st["static"] = [torch.empty_like(t) for t in tensors]

@@ -333,3 +333,44 @@ def test_lookahead_graph_replay_equals_eager(ops):
     assert n0 == n1
     assert torch.equal(d0, d1) and torch.equal(g0, g1)
     assert o0[-1]["g_loss"] == o1[-1]["g_loss"] and o0[-1]["d_m_loss"] == o1[-1]["d_m_loss"]
+
+
+def _seven_iterations(ops, nets, cfg, cm, ch, dx, graphs, two_streams):
+    from cycle_gan_rna_amd.engine import StepEngine
+    from cycle_gan_rna_amd.noise import DeviceNoise
+    eng = StepEngine(nets, cfg, cm, ch, ops, 32)
+    if two_streams:
+        eng.enable_concurrency()
+    if graphs:
+        eng.enable_graphs()
+    noise = DeviceNoise(ops.device, seed=7, default_generator=True)
+    for i in range(7):
+        noise.begin_step()
+        eng.iteration(i, *dx, noise)
+    torch.cuda.synchronize()
+    return eng.arena_d.p.clone(), eng.arena_g.p.clone()
+
+
+def test_engine_called_from_another_stream(ops):
+    """A caller's own stream (default priority) as the current stream gives the same bits as the device's default
+    stream in every execution mode.  From a stream of raised priority the single-stream modes work and the
+    concurrent ones are refused with an error: on this ROCm build their side-stream joins stop making progress."""
+    cfg = small_cfg(preprocess_type="log_normalized", nb_critic=2)
+    nets, xm, xh, lm, lh = make_problem(64, 64, 32, cfg)
+    cm, ch = O.centroid_table(xm, lm, 12), O.centroid_table(xh, lh, 12)
+    dx = [t.cuda() for t in (xm, xh, lm[:, None], lh[:, None])]
+    modes = ((False, False), (True, False), (False, True), (True, True))
+    base = {m: _seven_iterations(ops, nets, cfg, cm, ch, dx, *m) for m in modes}
+    with torch.cuda.stream(torch.cuda.Stream()):
+        for m in modes:
+            d, g = _seven_iterations(ops, nets, cfg, cm, ch, dx, *m)
+            assert torch.equal(d, base[m][0]) and torch.equal(g, base[m][1]), m
+    with torch.cuda.stream(torch.cuda.Stream(priority=-1)):
+        for m in modes:
+            if m[1]:
+                with pytest.raises(RuntimeError, match="default priority"):
+                    _seven_iterations(ops, nets, cfg, cm, ch, dx, *m)
+            else:
+                d, g = _seven_iterations(ops, nets, cfg, cm, ch, dx, *m)
+                assert torch.equal(d, base[m][0]) and torch.equal(g, base[m][1]), m
+    torch.cuda.synchronize()
