@@ -100,9 +100,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # RCCL in production; "gloo" lets several ranks share one GPU to rehearse this code path (RCCL refuses that)
+    backend = os.environ.get("CGRNA_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local %= torch.cuda.device_count()
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ.get("CGRNA_BENCH_WATCHDOG", "600")), exit=True)
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device("cuda", local)
 
     from cycle_gan_rna_amd.engine import StepEngine
@@ -171,7 +180,9 @@ def main():
     assert all(v == v and abs(v) < 1e30 for k, v in losses.items() if isinstance(v, float)), losses
 
     roof = None
+    eng.flush()                        # several ranks: apply the critic update that is still in flight
     if not a.no_roofline and rank == 0:
+        eng.sync.enabled = False       # only this rank runs the pass below, so it must not issue collectives
         # GEMM launches of NB_CRITIC iterations (4 critic + 1 generator step), launched one by one (no graph replay)
         # and each bracketed by HIP events on the launch stream.  A block of filler work is queued first so that the
         # host runs ahead of the GPU and the event pairs time the kernels, not the gaps between launches.
@@ -218,7 +229,7 @@ def main():
     if world > 1:
         dist.barrier()
     other = None
-    if a.dtype == "f32" and not a.no_bf16_line and not a.only:
+    if a.dtype == "f32" and not a.no_bf16_line and not a.only and world == 1:      # a one-GPU comparison
         # the named configuration compares float32 with bf16 MFMA: time the same step with the large dense-layer
         # products on the bf16 matrix cores (float32 operands rounded on the fly, float32 accumulate)
         ops16 = HipOps(dev, precision="bf16")

@@ -59,3 +59,22 @@ def test_two_ranks_on_one_gpu_stay_identical(tmp_path):
         assert torch.equal(r0["coef"], r1["coef"])
         res[graphs] = r0
     assert torch.equal(res[False]["d"], res[True]["d"]) and torch.equal(res[False]["g"], res[True]["g"])
+
+
+def test_bench_with_two_ranks(tmp_path):
+    """bench.py launched the way the driver launches it for N > 1 (one process per rank under torch.distributed.run),
+    with the two ranks sharing the test GPU over gloo: the timed loop, the max over ranks, the GEMM timing pass that
+    only rank 0 runs (it must not issue collectives the other rank does not join) and the one JSON line."""
+    import json
+    import subprocess
+    env = dict(os.environ, CGRNA_BENCH_BACKEND="gloo", CGRNA_BENCH_WATCHDOG="90")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(31600 + os.getpid() % 2000), os.path.join(ROOT, "bench.py"), "--gpus", "2",
+           "--steps", "4", "--warmup", "2", "--genes", "256", "--batch", "32"]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=110)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["config"]["global_batch"] == 64
+    assert out["value"] > 0 and out["roofline"]["achieved"] > 0 and out["cpu_baseline"] is None
