@@ -852,11 +852,13 @@ class EngineBase:
         self._cap_streams = {}
         self.use_graphs = True
 
-    def _graphed(self, kind, body, tensors, noise):
+    def _graphed(self, kind, body, tensors, noise, static=None):
+        """`static`: the fixed device buffers this graph reads its inputs from (default: buffers of its own).  Two
+        graphs that feed the same consumer must share them, because the consumer's graph holds their addresses."""
         self._check_stream_priority()
         st = self._graphs.setdefault(kind, dict(calls=0, graph=None, static=None, nbt=None))
         if st["static"] is None:
-            st["static"] = [torch.empty_like(t) for t in tensors]
+            st["static"] = list(static) if static is not None else [torch.empty_like(t) for t in tensors]
         for dst, src in zip(st["static"], tensors):
             dst.copy_(src)
         st["calls"] += 1
@@ -1349,6 +1351,9 @@ class StepEngine(EngineBase):
         self.gen_d = [{"g_m2h": GenPass(self, N["g_m2h"], gm, gh, B), "g_h2m": GenPass(self, N["g_h2m"], gh, gm, B)}
                       for _ in range(2)]
         self._d_states = [None, None]
+        # the batch of workspace set s has one fixed home: the set is filled either by "dgen{s}" or by
+        # "pair{1-s}n", and the critics' graphs that read it later are captured once, with these addresses
+        self._real = [None, None]
         self._dset = 0
         self._pre = None        # (workspace set, batch) of a critic-step forward already issued
         self.lookahead = True
@@ -1372,11 +1377,16 @@ class StepEngine(EngineBase):
                 self.noise.space = ""
             return self.ctx.__exit__(*exc)
 
-    def _run_graph_or_eager(self, kind, body, tensors, noise, b):
+    def _run_graph_or_eager(self, kind, body, tensors, noise, b, static=None):
         if self.use_graphs and b == self.max_b:
-            self._graphed(kind, body, tensors, noise)
+            self._graphed(kind, body, tensors, noise, static)
         else:
             body(*tensors, noise)
+
+    def _real_set(self, s, like):
+        if self._real[s] is None:
+            self._real[s] = [torch.empty_like(t) for t in like]
+        return self._real[s]
 
     def _d_gen_set(self, s):
         def body(mouse, human, mouse_cat, human_cat, noise):
@@ -1446,7 +1456,7 @@ class StepEngine(EngineBase):
             s = self._pre[0]
         else:                   # nothing (or some other batch) was issued ahead: forward now
             s = self._dset = 1 - self._dset
-            self._run_graph_or_eager(f"dgen{s}", self._d_gen_set(s), ins, noise, b)
+            self._run_graph_or_eager(f"dgen{s}", self._d_gen_set(s), ins, noise, b, self._real_set(s, ins))
         self._pre = None
         self._begin_opt(self.arena_d, self.lr_d)
         if do_g:
@@ -1454,7 +1464,8 @@ class StepEngine(EngineBase):
             self._run_graph_or_eager(f"pair{s}g", self._pair_body(s, "g"), ins, noise, b)
         elif nxt is not None and nxt[0].shape[0] == b:
             self._dset = 1 - s
-            self._run_graph_or_eager(f"pair{s}n", self._pair_body(s, "n"), tuple(nxt), noise, b)
+            self._run_graph_or_eager(f"pair{s}n", self._pair_body(s, "n"), tuple(nxt), noise, b,
+                                     self._real_set(1 - s, nxt))
             self._pre = (1 - s, key(nxt))
         else:
             self._run_graph_or_eager(f"dcrit{s}", self._d_crit_set(s), (), noise, b)

@@ -155,8 +155,8 @@ def test_train_function_against_reference(tag):
     assert float((got - ref_final["values"].double()).norm() / upd_ref.norm()) <= 0.35
 
 
-@pytest.mark.parametrize("identity", [False, True])
-def test_train_function_default_mode_replays_graphs(identity):
+@pytest.mark.parametrize("identity,iters_per_epoch", [(False, 1), (True, 1), (False, 7)])
+def test_train_function_default_mode_replays_graphs(identity, iters_per_epoch):
     """Default mode of the drop-in loop (noise drawn in HBM): the step runs as HIP graphs on several streams.  With
     the same seed, a run that launches every kernel eagerly on one stream gives the same metrics bit for bit.
     identity: the same with the identity-loss extension switched on (one gene list for both species)."""
@@ -164,6 +164,7 @@ def test_train_function_default_mode_replays_graphs(identity):
     from oracle import cyclegan_oracle as O
     fx = torch.load(os.path.join(GOLD, "function_level.pt"), weights_only=True)["one_iter_epochs"]
     gm, gh, N = fx["g_mouse"], fx["g_human"], fx["N"]
+    N *= iters_per_epoch        # several iterations per epoch: generator forwards are issued ahead, across batches
     if identity:
         gh = gm
     xm, _ = O.synthetic_expression(N, gm, 12, seed=3)

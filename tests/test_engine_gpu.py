@@ -320,19 +320,34 @@ def test_lookahead_schedule_equals_plain_schedule(ops, nb_critic):
             assert torch.equal(b0[net][k], b1[net][k]), (net, k)
 
 
-def test_lookahead_graph_replay_equals_eager(ops):
-    cfg = small_cfg(preprocess_type="log_normalized", nb_critic=2)
+@pytest.mark.parametrize("nb_critic,iters", [(2, 11), (3, 14), (4, 18), (5, 17)])
+def test_lookahead_graph_replay_equals_eager(ops, nb_critic, iters):
+    """Graphs + lookahead against eager launches of the plain schedule, bit for bit, with every iteration on a
+    different batch.  A workspace set of the critic step is filled by one of two graphs (the forward issued when
+    nothing was issued ahead, or the forward riding beside the other set's critics); the critics' graphs are captured
+    once and must see the batch whichever of the two filled the set, which shows from nb_critic = 3 on and only
+    after both providers have been replayed (iteration 2*nb_critic + 1 and later)."""
+    cfg = small_cfg(preprocess_type="log_normalized", nb_critic=nb_critic)
     B = 32
-    nets, xm, xh, lm, lh = make_problem(64, 64, 2 * B, cfg)
+    nets, xm, xh, lm, lh = make_problem(64, 64, 7 * B, cfg)       # 7 distinct batches, co-prime with the cadences
     cm, ch = O.centroid_table(xm, lm, 12), O.centroid_table(xh, lh, 12)
     data = [t.cuda() for t in (xm, xh, lm[:, None], lh[:, None])]
     from cycle_gan_rna_amd.noise import DeviceNoise
-    runs = [_run_schedule(ops, nets, cfg, cm, ch, data, B, 11, True, gr,
-                          lambda: DeviceNoise(ops.device, seed=7, default_generator=True)) for gr in (False, True)]
-    (d0, g0, o0, n0, _), (d1, g1, o1, n1, _) = runs
-    assert n0 == n1
-    assert torch.equal(d0, d1) and torch.equal(g0, g1)
-    assert o0[-1]["g_loss"] == o1[-1]["g_loss"] and o0[-1]["d_m_loss"] == o1[-1]["d_m_loss"]
+    mk = lambda: DeviceNoise(ops.device, seed=7, default_generator=True)  # noqa: E731
+    runs = [_run_schedule(ops, nets, cfg, cm, ch, data, B, iters, la, gr, mk)
+            for la, gr in ((False, False), (True, False), (True, True))]
+    d0, g0, o0, n0, b0 = runs[0]
+    for d1, g1, o1, n1, b1 in runs[1:]:
+        assert n0 == n1
+        assert torch.equal(d0, d1) and torch.equal(g0, g1)
+        for a, b in zip(o0, o1):
+            assert a.keys() == b.keys()
+            for k in a:
+                if k != "scales":
+                    assert a[k] == b[k], k
+        for net in b0:
+            for k in b0[net]:
+                assert torch.equal(b0[net][k], b1[net][k]), (net, k)
 
 
 def _seven_iterations(ops, nets, cfg, cm, ch, dx, graphs, two_streams):
