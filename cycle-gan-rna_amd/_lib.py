@@ -30,6 +30,7 @@ SIGNATURES = {
     "cg_gemm": ([P, I, P, I, P, I, I, I, I, I, I, I, P, I, P, I, P, I, F, I, P, Z, P], I),
     "cg_bn_workspace_bytes": ([I, I], Z),
     "cg_bn_fwd": ([P, I, P, I, I, I, P, P, F, P, P, P, P, F, F, P, I, P, I, P, I, P, Z, P], I),
+    "cg_bn_fwd_static": ([P, I, P, I, I, I, P, P, F, P, P, P, P, F, F, P, I, P, I, P, I, P], I),
     "cg_bn_fwd_seg": ([P, I, P, I, I, I, C.c_uint, I, P, P, F, P, P, P, P, F, F, P, I, P, I, P, I, P, Z, P], I),
     "cg_bn_bwd_seg": ([P, I, P, I, P, I, P, I, P, I, P, P, P, P, P, I, P, P, F, I, I, I, P, Z, P], I),
     "cg_tok_blocks": ([I], I),

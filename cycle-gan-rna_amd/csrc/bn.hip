@@ -10,7 +10,14 @@
 //           statistics and applies them to its rows
 // so tall-skinny (8192 x 16) and short-wide (512 x 2048) inputs both spread
 // over hundreds of workgroups.
+#include <mutex>
 #include "common.h"
+
+// Scratch of cg_bn_fwd_static: the per-chunk column sums of the two-launch forward, for callers that cannot
+// allocate.  One copy per GPU, held until the process ends.  In host code this name is only a handle for
+// hipGetSymbolAddress; kernels are handed the device address it returns (static_scratch()).
+constexpr size_t BN_STATIC_BYTES = (size_t)1 << 20;
+static __device__ __align__(256) unsigned char scratch[BN_STATIC_BYTES];
 
 namespace {
 
@@ -445,6 +452,41 @@ extern "C" int cg_bn_fwd(float* Y, int ldy, const float* X, int ldx, int M, int 
                          void* stream) {
   return cg_bn_fwd_seg(Y, ldy, X, ldx, M, 1, 0u, N, gamma, beta, eps, mean_out, invstd_out, running_mean, running_var,
                        momentum, slope, mask, ldmask, pm_out, ldpm, ybf16, ldybf16, workspace, workspace_bytes, stream);
+}
+
+// Device address of `scratch` on the current device, looked up once per device.
+static int static_scratch(void** out) {
+  constexpr int MAX_DEV = 64;
+  static void* ptrs[MAX_DEV] = {nullptr};
+  static std::mutex mu;
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  if (dev < 0 || dev >= MAX_DEV) return CG_ERR_UNSUPPORTED;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!ptrs[dev]) {
+    void* p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return (int)e;
+    if (!p) return CG_ERR_UNSUPPORTED;
+    ptrs[dev] = p;
+  }
+  *out = ptrs[dev];
+  return CG_OK;
+}
+
+extern "C" int cg_bn_fwd_static(float* Y, int ldy, const float* X, int ldx, int M, int N, const float* gamma,
+                                const float* beta, float eps, float* mean_out, float* invstd_out, float* running_mean,
+                                float* running_var, float momentum, float slope, const float* mask, int ldmask,
+                                float* pm_out, int ldpm, void* ybf16, int ldybf16, void* stream) {
+  if (M <= 0 || N <= 0) return CG_ERR_BAD_ARG;
+  if (cg_bn_workspace_bytes(M, N) > BN_STATIC_BYTES) return CG_ERR_WORKSPACE;   // more columns than the array holds sums for
+  void* ws = nullptr;
+  const int st = static_scratch(&ws);
+  if (st != CG_OK) return st;
+  // every partial sum the second launch reads is written by the first, so nothing in the array has to start at zero
+  return cg_bn_fwd_seg(Y, ldy, X, ldx, M, 1, 0u, N, gamma, beta, eps, mean_out, invstd_out, running_mean, running_var,
+                       momentum, slope, mask, ldmask, pm_out, ldpm, ybf16, ldybf16, ws, BN_STATIC_BYTES, stream);
 }
 
 extern "C" int cg_bn_eval(float* Y, int ldy, const float* X, int ldx, int M, int N, const float* gamma,

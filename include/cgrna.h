@@ -89,6 +89,23 @@ int cg_bn_fwd(float* Y, int ldy, const float* X, int ldx, int M, int N,
               void* ybf16, int ldybf16, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * cg_bn_fwd for callers that cannot allocate device memory or hand in a workspace (code under HIP graph capture,
+ * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  The per-chunk column
+ * sums live in a 1 MiB array inside the library's device image (one copy per GPU, held until the process ends);
+ * the call makes no hipMalloc / hipFree and no allocating library call.  Same arguments, kernels and results as
+ * cg_bn_fwd.  Shapes whose sums do not fit - cg_bn_workspace_bytes(M, N) > 1 MiB, i.e. more than 43690 columns -
+ * return CG_ERR_WORKSPACE.  Every call on one GPU shares that GPU's array: calls that overlap on one GPU (two
+ * streams) race; calls on one stream are safe.  The first call on a device looks up the array's address
+ * (hipGetSymbolAddress); make it outside a stream capture.
+ */
+int cg_bn_fwd_static(float* Y, int ldy, const float* X, int ldx, int M, int N,
+                     const float* gamma, const float* beta, float eps,
+                     float* mean_out, float* invstd_out,
+                     float* running_mean, float* running_var, float momentum,
+                     float slope, const float* mask, int ldmask, float* pm_out, int ldpm,
+                     void* ybf16, int ldybf16, void* stream);
+
+/*
  * cg_bn_fwd on `nseg` (1..8) equal row segments of X at once: segment s is rows
  * [s*seg_rows, (s+1)*seg_rows) and is normalised with its own batch statistics,
  * exactly as a separate call of the module on that batch would
