@@ -96,8 +96,23 @@ def main():
     ap.add_argument("--eager", action="store_true", help="launch every kernel from Python instead of replaying HIP graphs")
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks as fresh child processes (this process has made no
+        # GPU call yet and makes none), one per GPU, and relay their output; rank 0 prints the JSON line
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.run(cmd).returncode)
+
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus != world:
+        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch one process per GPU "
+                 f"(python -m torch.distributed.run --nproc-per-node {a.gpus} bench.py --gpus {a.gpus} ...)")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # RCCL in production; "gloo" lets several ranks share one GPU to rehearse this code path (RCCL refuses that)

@@ -37,6 +37,7 @@ import torch
 import torch.nn as nn
 
 from .engine import Arena, DiscPass, GenPass, Net, StepEngine, split_state, _arena_order
+from .autograd_guard import first_order_only
 from .noise import DeviceNoise, HostReplayNoise
 
 try:                                   # optional, as in the reference (:21-25)
@@ -120,6 +121,7 @@ class _AttnFn(torch.autograd.Function):
         return y.view(x.shape)
 
     @staticmethod
+    @first_order_only
     def backward(ctx, dy):
         xc, flat, keep = ctx.saved_tensors
         ops = _ops(dy.device)
@@ -188,6 +190,7 @@ class _ResBlockFn(torch.autograd.Function):
         return y.view(x.shape)
 
     @staticmethod
+    @first_order_only
     def backward(ctx, dy):
         if ctx.eval_mode:
             raise RuntimeError("ResidualBlock backward is implemented for train mode")
@@ -293,6 +296,7 @@ class _GenFn(torch.autograd.Function):
         return out.clone(), p.mu().clone(), p.log_var().clone()
 
     @staticmethod
+    @first_order_only
     def backward(ctx, d_out, d_mu, d_lv):
         be, p = ctx.be, ctx.p
         be.arena.g.zero_()
@@ -314,6 +318,7 @@ class _DiscFn(torch.autograd.Function):
         return val.clone(), feat.clone()
 
     @staticmethod
+    @first_order_only
     def backward(ctx, d_val, d_feat):
         be, p = ctx.be, ctx.p
         ops = be.ops
@@ -451,6 +456,7 @@ class _GPFn(torch.autograd.Function):
         return tot.float().reshape(())
 
     @staticmethod
+    @first_order_only
     def backward(ctx, dgp):
         s = dgp.float()
         d_real = ctx.alpha * ctx.dxh * s if ctx.need[0] else None

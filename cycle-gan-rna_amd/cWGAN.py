@@ -29,6 +29,7 @@ import torch.nn as nn
 
 from .cwgan_engine import CriticW, CwganEngine, GenW
 from .engine import Arena, Net, split_state
+from .autograd_guard import first_order_only
 from .noise import DeviceNoise, HostReplayNoise
 
 try:                                   # optional, as in the notebook (cell 0 imports it, cell 3 checks wandb.run)
@@ -112,6 +113,7 @@ class _GenFn(torch.autograd.Function):
         return out.clone()
 
     @staticmethod
+    @first_order_only
     def backward(ctx, d_out):
         be, p = ctx.be, ctx.p
         if not be.module.training:
@@ -136,6 +138,7 @@ class _DiscFn(torch.autograd.Function):
         return val.clone()
 
     @staticmethod
+    @first_order_only
     def backward(ctx, d_val):
         be, p, b = ctx.be, ctx.p, ctx.b
         be.arena.g.zero_()
@@ -168,6 +171,7 @@ class _GPFn(torch.autograd.Function):
         return tot.float().reshape(())
 
     @staticmethod
+    @first_order_only
     def backward(ctx, dgp):
         s = dgp.float()
         return (None, None, None, None, None, None, *[g * s for g in ctx.grads])

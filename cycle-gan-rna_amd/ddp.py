@@ -27,37 +27,45 @@ class GradSync:
         self.bucket_elems = bucket_bytes // 4
         self.comm = torch.cuda.Stream(device=self.device) if (self.enabled and self.is_cuda) else None
         self.pending = []
-        # The gloo backend stages device tensors through the host on a helper thread; issued right behind a HIP
-        # graph replay that staging never completes on this stack, so gloo (CPU clusters and tests; RCCL is the
-        # production backend) gets a host synchronisation before every collective.
+        # The gloo backend (CPU clusters and tests; RCCL is the production backend) stages a device tensor through
+        # the host on a stream of its own, which it makes wait for the calling stream.  On this stack that wait does
+        # not complete (or takes seconds) when the calling stream still has a kernel in flight - reproduced without
+        # this package by tools/diag_gloo_allreduce.py: all_reduce, a scaling kernel, all_reduce on one stream stalls
+        # in the second call; with the stream drained before each call it never does.  So gloo gets a drained
+        # stream before every collective.
         self.host_sync = self.enabled and self.is_cuda and dist.get_backend() == "gloo"
 
-    def launch(self, flat_grad):
-        """Start averaging `flat_grad` (a contiguous 1-D view whose producer kernels
-        have been enqueued on the current stream)."""
+    def launch(self, flat_grad, ranges=None):
+        """Start averaging `flat_grad` (a contiguous 1-D tensor) over the ranks, or only its element ranges
+        [(lo, hi), ...], whose producer kernels have been enqueued on the current stream.  Buckets of at most
+        bucket_bytes go out on the side stream in the order given; wait() joins them."""
         if not self.enabled:
+            return
+        if ranges is None:
+            ranges = [(0, flat_grad.numel())]
+        chunks = [flat_grad[s:min(s + self.bucket_elems, hi)] for lo, hi in ranges if hi > lo
+                  for s in range(lo, hi, self.bucket_elems)]
+        if not self.is_cuda:   # CPU tensors (gloo tests)
+            for chunk in chunks:
+                dist.all_reduce(chunk, op=dist.ReduceOp.SUM)
+                chunk.div_(self.world)
             return
         if self.host_sync:
             torch.cuda.synchronize(self.device)
-        if self.is_cuda:
-            ready = torch.cuda.Event()
-            ready.record(torch.cuda.current_stream(self.device))
-            self.comm.wait_event(ready)
-            with torch.cuda.stream(self.comm):
-                for s in range(0, flat_grad.numel(), self.bucket_elems):
-                    chunk = flat_grad[s:s + self.bucket_elems]
-                    # sum + scale rather than ReduceOp.AVG: identical on RCCL, and also valid on gloo, which lets
-                    # the device code path be exercised by two ranks sharing one GPU
-                    dist.all_reduce(chunk, op=dist.ReduceOp.SUM)
-                    chunk.mul_(1.0 / self.world)
-            done = torch.cuda.Event()
-            done.record(self.comm)
-            self.pending.append(done)
-        else:   # CPU tensors (gloo tests)
-            for s in range(0, flat_grad.numel(), self.bucket_elems):
-                chunk = flat_grad[s:s + self.bucket_elems]
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.device))
+        self.comm.wait_event(ready)
+        with torch.cuda.stream(self.comm):
+            for chunk in chunks:
+                if self.host_sync:
+                    self.comm.synchronize()
+                # sum + scale rather than ReduceOp.AVG: identical on RCCL, and also valid on gloo, which lets
+                # the device code path be exercised by two ranks sharing one GPU
                 dist.all_reduce(chunk, op=dist.ReduceOp.SUM)
-                chunk.div_(self.world)
+                chunk.mul_(1.0 / self.world)
+        done = torch.cuda.Event()
+        done.record(self.comm)
+        self.pending.append(done)
 
     def wait(self):
         """Make the current stream wait for every launched bucket."""

@@ -54,6 +54,24 @@ class GlobalRngNoise:
         return torch.rand(shape)
 
 
+class GeneratorNoise:
+    """GlobalRngNoise drawing from a generator of its own: after Generator().manual_seed(s) it sees the numbers the
+    global generator gives after torch.manual_seed(s), so several replicas of the step (one per emulated rank) can
+    be advanced side by side in one process."""
+
+    def __init__(self, seed):
+        self.gen = torch.Generator().manual_seed(seed)
+
+    def randn(self, shape, dtype):
+        return torch.randn(shape, dtype=dtype, generator=self.gen)
+
+    def keep(self, shape, p_drop, dtype):
+        return torch.empty(shape, dtype=dtype).bernoulli_(1.0 - p_drop, generator=self.gen).div_(1.0 - p_drop)
+
+    def rand(self, shape):
+        return torch.rand(shape, generator=self.gen)
+
+
 class RecordedNoise:
     """Replays a list of tensors (in draw order) and checks shapes."""
 
@@ -379,8 +397,8 @@ class OracleTrainer:
     def D(self, which, x, cat):
         return discriminator_forward(self.nets[which], x, cat, self.noise, train=True)
 
-    def d_step(self, mouse, human, mouse_cat, human_cat):
-        """GAN_functions.py:322-340."""
+    def d_step(self, mouse, human, mouse_cat, human_cat, step=True):
+        """GAN_functions.py:322-340.  step=False stops before the optimizer steps (gradients left in .grad)."""
         cfg = self.cfg
         self.opt_dm.zero_grad()
         self.opt_dh.zero_grad()
@@ -399,12 +417,20 @@ class OracleTrainer:
 
         d_m_loss.backward()
         d_h_loss.backward()
-        self.opt_dm.step()
-        self.opt_dh.step()
+        if step:
+            self.opt_dm.step()
+            self.opt_dh.step()
         return dict(d_m_loss=d_m_loss.item(), d_h_loss=d_h_loss.item(), gp_m=gp_m.item(), gp_h=gp_h.item())
 
     def g_step(self, mouse, human, mouse_cat, human_cat):
         """GAN_functions.py:343-419."""
+        L = self.g_losses(mouse, human, mouse_cat, human_cat)
+        if self.ext_weights is None:
+            self.g_scales({k: L[k].item() for k in ("g_adv", "g_cycle", "g_celltype", "g_fm", "kl")})
+        return self.g_finish(L)
+
+    def g_losses(self, mouse, human, mouse_cat, human_cat):
+        """:343-376: forward passes and the loss terms (tensors with their graphs)."""
         cfg = self.cfg
         F = torch.nn.functional
         self.opt_g.zero_grad()
@@ -439,35 +465,53 @@ class OracleTrainer:
         kl = -0.5 * torch.mean(1 + lv_h - mu_h.pow(2) - lv_h.exp()) \
              - 0.5 * torch.mean(1 + lv_m - mu_m.pow(2) - lv_m.exp())   # :375-376
 
+        return dict(g_adv=g_adv, g_cycle=g_cycle, g_celltype=g_celltype, g_fm=g_fm, kl=kl, g_identity=g_identity,
+                    fake_human=fake_human, fake_mouse=fake_mouse)
+
+    def g_scales(self, v):
+        """:380-399: moving averages of the five loss values `v` (Python floats) and the scales derived from them."""
+        a = 0.3                                                  # :288, :380-384
+        e = self.ema
+        e["adv"] = a * v["g_adv"] + (1 - a) * e["adv"]
+        e["cycle"] = a * v["g_cycle"] + (1 - a) * e["cycle"]
+        e["celltype"] = a * v["g_celltype"] + (1 - a) * e["celltype"]
+        e["fm"] = a * v["g_fm"] + (1 - a) * e["fm"]
+        e["kl"] = a * v["kl"] + (1 - a) * e["kl"]
+        s = dict(adv=1 / (abs(e["adv"]) + 1e-8), cycle=1 / (e["cycle"] + 1e-8),       # :387-391
+                 celltype=1 / (e["celltype"] + 1e-8), fm=1 / (e["fm"] + 1e-8), kl=1 / (e["kl"] + 1e-8))
+        mn = min(s.values())                                     # :394-399
+        s = {k: val / mn for k, val in s.items()}
+        self.scales = s
+        return s
+
+    def g_finish(self, L, step=True):
+        """:402-419: weighted sum with the scales of g_scales(), backward, optimizer step (step=False stops before
+        it), metrics."""
+        cfg = self.cfg
+        g_adv, g_cycle, g_celltype, g_fm, kl, g_identity = (L[k] for k in ("g_adv", "g_cycle", "g_celltype", "g_fm",
+                                                                             "kl", "g_identity"))
+        fake_human, fake_mouse = L["fake_human"], L["fake_mouse"]
+        lam_id = float(cfg.get("lambda_identity", 0.0))
         if self.ext_weights is not None:
             w = self.ext_weights
             g_loss = w[0] * g_adv + w[1] * g_cycle + w[2] * g_celltype + w[3] * g_fm + w[4] * kl + lam_id * g_identity
             g_loss.backward()
-            self.opt_g.step()
+            if step:
+                self.opt_g.step()
             return dict(g_loss=g_loss.item(), g_adv=g_adv.item(), cycle_loss=g_cycle.item(),
                         celltype_loss=g_celltype.item(), fm_loss=g_fm.item(), kl_loss=kl.item(),
                         fake_human_var=torch.var(fake_human.detach(), dim=0).mean().item(),
                         fake_mouse_var=torch.var(fake_mouse.detach(), dim=0).mean().item(),
                         fake_human=fake_human.detach(), fake_mouse=fake_mouse.detach())
-        a = 0.3                                                  # :288, :380-384
-        e = self.ema
-        e["adv"] = a * g_adv.item() + (1 - a) * e["adv"]
-        e["cycle"] = a * g_cycle.item() + (1 - a) * e["cycle"]
-        e["celltype"] = a * g_celltype.item() + (1 - a) * e["celltype"]
-        e["fm"] = a * g_fm.item() + (1 - a) * e["fm"]
-        e["kl"] = a * kl.item() + (1 - a) * e["kl"]
-        s = dict(adv=1 / (abs(e["adv"]) + 1e-8), cycle=1 / (e["cycle"] + 1e-8),       # :387-391
-                 celltype=1 / (e["celltype"] + 1e-8), fm=1 / (e["fm"] + 1e-8), kl=1 / (e["kl"] + 1e-8))
-        mn = min(s.values())                                     # :394-399
-        s = {k: v / mn for k, v in s.items()}
-        self.scales = s
+        s, e = self.scales, self.ema
         g_loss = (cfg["lambda_adv"] * s["adv"] * g_adv + cfg["lambda_cycle"] * s["cycle"] * g_cycle +
                   cfg["lambda_celltype"] * s["celltype"] * g_celltype + cfg["lambda_fm"] * s["fm"] * g_fm +
                   cfg["lambda_kl"] * s["kl"] * kl)               # :402-406
         if lam_id > 0:
             g_loss = g_loss + lam_id * g_identity
         g_loss.backward()
-        self.opt_g.step()
+        if step:
+            self.opt_g.step()
         return dict(g_loss=g_loss.item(), g_adv=g_adv.item(), cycle_loss=g_cycle.item(),
                     celltype_loss=g_celltype.item(), fm_loss=g_fm.item(), kl_loss=kl.item(),
                     identity_loss=g_identity.item(),

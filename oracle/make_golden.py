@@ -14,7 +14,7 @@ noise tensors in draw order, so that the fixtures stay valid on another torch
 build.  The same run cross-checks oracle/cyclegan_oracle.py against the
 reference and prints the largest deviations.
 
-    python oracle/make_golden.py [--only module|func|traj]
+    python oracle/make_golden.py [--only fp64|module|func|func_unequal|traj]
 """
 from __future__ import annotations
 
@@ -210,9 +210,10 @@ def run_reference_function(R, cfg, gm, gh, N, init_seed, data_seed, train_seed):
     from sklearn.preprocessing import StandardScaler
     ref, nets = check_init(R, cfg, gm, gh, init_seed)
     g_m2h, g_h2m, d_m, d_h = ref
-    xm, lm = O.synthetic_expression(N, gm, 12, seed=data_seed)
-    xh, lh = O.synthetic_expression(N, gh, 12, seed=data_seed + 1)
-    lm, lh = O.balanced_labels(N, 12, data_seed + 2), O.balanced_labels(N, 12, data_seed + 3)
+    n_mouse, n_human = (N, N) if isinstance(N, int) else N       # the two species may have different cell counts
+    xm, lm = O.synthetic_expression(n_mouse, gm, 12, seed=data_seed)
+    xh, lh = O.synthetic_expression(n_human, gh, 12, seed=data_seed + 1)
+    lm, lh = O.balanced_labels(n_mouse, 12, data_seed + 2), O.balanced_labels(n_human, 12, data_seed + 3)
     names = [f"type{i:02d}" for i in range(12)]
     idx_to_ct = {i: n for i, n in enumerate(names)}
     mouse_ad, human_ad = Obs([names[i] for i in lm.tolist()]), Obs([names[i] for i in lh.tolist()])
@@ -278,6 +279,25 @@ def function_level(R):
                          for m, name in zip(ref, ['g_m2h', 'g_h2m', 'd_m', 'd_h'])})
         out[tag] = fx
     torch.save(out, os.path.join(GOLD, "function_level.pt"))
+
+
+def function_level_unequal(R):
+    """Different cell counts for the two species: the shorter loader runs out in the middle of an epoch, is
+    restarted and re-shuffled (GAN_functions.py:299-309), and ragged last batches of either loader are truncated
+    to the smaller of the pair (:315-319).  40 mouse cells = batches of 16, 16, 8; 88 human cells = 16 x 5, 8;
+    six iterations per epoch, the mouse loader restarting at the fourth."""
+    cfg = small_cfg(epochs=3, batch_size=16, nb_critic=2, preprocess_type='log_normalized', decay_start_epoch=1,
+                    decay_type='cosine')
+    gm, gh, N = 64, 56, (40, 88)
+    ref, nets, data, metrics = run_reference_function(R, cfg, gm, gh, N, init_seed=3, data_seed=200, train_seed=13)
+    tr, metrics2 = run_oracle_function(nets, cfg, data, train_seed=13)
+    compare_function("unequal_restart", ref, tr, metrics, metrics2)
+    fx = dict(torch_version=str(torch.__version__), cfg={k: v for k, v in cfg.items() if k != 'device'},
+              g_mouse=gm, g_human=gh, N=list(N), init_seed=3, data_seed=200, train_seed=13,
+              metrics={k: [float(v) for v in vals] for k, vals in metrics.items()},
+              final={name: {k: sample(v) for k, v in m.state_dict().items()}
+                     for m, name in zip(ref, ['g_m2h', 'g_h2m', 'd_m', 'd_h'])})
+    torch.save({"unequal_restart": fx}, os.path.join(GOLD, "function_level_unequal.pt"))
 
 
 def trajectory_level(R):
@@ -359,5 +379,7 @@ if __name__ == "__main__":
         module_level(R)
     if a.only in (None, "func"):
         function_level(R)
+    if a.only in (None, "func_unequal"):
+        function_level_unequal(R)
     if a.only in (None, "traj"):
         trajectory_level(R)

@@ -38,3 +38,34 @@ def update_rel_l2(final, ref_final, init):
 
 LOSS_KEYS = ('d_m_loss', 'd_h_loss', 'g_loss', 'g_adv', 'cycle_loss', 'celltype_loss', 'fm_loss', 'kl_loss',
              'fake_human_var', 'fake_mouse_var')
+
+
+class _WideNoise(O.GlobalRngNoise):
+    """The float32 draws of GlobalRngNoise, widened: a float64 run of the oracle sees the same noise values."""
+
+    def randn(self, shape, dtype):
+        return torch.randn(shape, dtype=torch.float32).to(dtype)
+
+    def keep(self, shape, p_drop, dtype):
+        return super().keep(shape, p_drop, torch.float32).to(dtype)
+
+
+def oracle_iteration_grads(nets, cfg, cm, ch, xm, xh, lm, lh, dtype, seed):
+    """One critic step + one generator step of the oracle in `dtype` on the noise that torch.manual_seed(seed) gives
+    in float32.  Returns (metrics, {(net, key): gradient}) - critic gradients as the critic step leaves them,
+    generator gradients as the generator step (run after the critic update, like the loop body) leaves them."""
+    cast = lambda t: t.to(dtype) if t.is_floating_point() else t  # noqa: E731
+    tr = O.OracleTrainer({n: {k: cast(v) for k, v in sd.items()} for n, sd in nets.items()}, cfg, cast(cm), cast(ch),
+                         noise=_WideNoise())
+    torch.manual_seed(seed)
+    out = tr.d_step(cast(xm), cast(xh), lm, lh, step=False)
+    grads = {(n, k): tr.nets[n][k].grad.clone() for n in ("d_m", "d_h") for k in O.param_names(tr.nets[n])
+             if tr.nets[n][k].grad is not None}
+    tr.opt_dm.step()
+    tr.opt_dh.step()
+    L = tr.g_losses(cast(xm), cast(xh), lm, lh)
+    tr.g_scales({k: L[k].item() for k in ("g_adv", "g_cycle", "g_celltype", "g_fm", "kl")})
+    out.update(tr.g_finish(L, step=False))
+    grads.update({(n, k): tr.nets[n][k].grad.clone() for n in ("g_m2h", "g_h2m") for k in O.param_names(tr.nets[n])
+                  if tr.nets[n][k].grad is not None})
+    return out, grads

@@ -78,3 +78,31 @@ def test_two_rank_step_equals_gradient_averaging(tmp_path):
         ops.adam(eng.arena_d.p, eng.arena_d.g, eng.arena_d.m, eng.arena_d.v, eng.arena_d.vmax, eng.arena_d.lr_step,
                  0.5, 0.9, 1e-8)
     assert float((engines[0].arena_d.p - r0["d"]).abs().max()) <= 1e-6
+
+
+def test_two_rank_step_matches_replicated_oracle(tmp_path):
+    """The same two-rank run against the oracle's emulation of data parallelism (oracle/ddp_emulation.py): replicas
+    with their own noise, averaged gradients, averaged loss values behind the loss scales."""
+    world, port = 2, 29400 + os.getpid() % 2000
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(tmp_path / "rank0.pt", weights_only=True)
+    sys.path.insert(0, ROOT)
+    from oracle.ddp_emulation import ReplicatedTrainer
+    from cycle_gan_rna_amd.engine import StepEngine
+    from oracle.ops_cpu import CpuOps
+    cfg, nets, xm, xh, lm, lh, cm, ch = _problem()
+    b = xm.shape[0] // world
+    rt = ReplicatedTrainer(nets, cfg, cm, ch, seeds=[100, 101])
+    out = rt.iteration(0, [(xm[k * b:(k + 1) * b], xh[k * b:(k + 1) * b], lm[k * b:(k + 1) * b], lh[k * b:(k + 1) * b])
+                           for k in range(world)])
+    assert abs(out["g_loss"] - r0["g_loss"]) <= 1e-4 * max(abs(out["g_loss"]), 0.5)
+    # parameters: lay the oracle's tensors out like the engine's arenas and compare the applied update
+    eng = StepEngine(nets, cfg, cm, ch, CpuOps(), b)
+    tr = rt.replicas[0]
+    for arena, key in ((eng.arena_d, "d"), (eng.arena_g, "g")):
+        ref, init = torch.zeros_like(arena.p), arena.p.clone()
+        for (net, k), (off, n, shape) in arena.offsets.items():
+            ref[off:off + n] = tr.nets[net][k].detach().reshape(-1)
+        moved = (ref - init).abs() > 0.5 * cfg["lr"]
+        d = (r0[key][moved].double() - ref[moved].double()).norm() / (ref[moved].double() - init[moved].double()).norm()
+        assert float(d) <= 5e-2, (key, float(d))

@@ -61,20 +61,112 @@ def test_two_ranks_on_one_gpu_stay_identical(tmp_path):
     assert torch.equal(res[False]["d"], res[True]["d"]) and torch.equal(res[False]["g"], res[True]["g"])
 
 
-def test_bench_with_two_ranks(tmp_path):
-    """bench.py launched the way the driver launches it for N > 1 (one process per rank under torch.distributed.run),
-    with the two ranks sharing the test GPU over gloo: the timed loop, the max over ranks, the GEMM timing pass that
-    only rank 0 runs (it must not issue collectives the other rank does not join) and the one JSON line."""
+def _oracle_worker(rank, world, port, out, gm, gh, b, iters):
+    import faulthandler
+    faulthandler.dump_traceback_later(100, exit=True)
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    from cycle_gan_rna_amd.engine import StepEngine
+    from cycle_gan_rna_amd.noise import HostReplayNoise
+    from cycle_gan_rna_amd.ops import HipOps
+    from oracle import cyclegan_oracle as O
+    from tests.helpers import make_problem, small_cfg
+    cfg = small_cfg(preprocess_type="log_normalized", nb_critic=2)
+    nets, xm, xh, lm, lh = make_problem(gm, gh, world * b, cfg)
+    cm, ch = O.centroid_table(xm, lm, 12), O.centroid_table(xh, lh, 12)
+    sl = slice(rank * b, (rank + 1) * b)
+    eng = StepEngine(nets, cfg, cm, ch, HipOps("cuda:0"), b)
+    torch.manual_seed(100 + rank)            # the rank's own noise, drawn with the reference's calls
+    noise = HostReplayNoise("cuda:0")
+    sh = (xm[sl].cuda(), xh[sl].cuda(), lm[sl, None].cuda(), lh[sl, None].cuda())
+    res = [eng.iteration(i, *sh, noise) for i in range(iters)]
+    torch.cuda.synchronize()
+    torch.save(dict(res=res, sd={n: eng.state_dict(n) for n in ("g_m2h", "g_h2m", "d_m", "d_h")}),
+               os.path.join(out, f"oracle_rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_two_ranks_match_gradient_averaging_oracle(tmp_path):
+    """Two ranks (HIP kernels, the ranks' collectives over gloo) against the oracle's emulation of batch-sharded data
+    parallelism: replicas with identical weights, each on its shard with its own noise, gradients averaged before
+    every optimizer step, the five generator loss values averaged before the loss scales are derived.  First
+    iteration to the float32 bar (1e-4), the third (second generator step) to 5e-3, parameter updates like
+    test_engine_gpu.check_updates."""
+    from oracle import cyclegan_oracle as O
+    from oracle.ddp_emulation import ReplicatedTrainer
+    from tests.helpers import LOSS_KEYS, make_problem, rel, small_cfg, update_rel_l2
+    world, port, gm, gh, b, iters = 2, 29700 + os.getpid() % 2000, 72, 64, 24, 3
+    mp.spawn(_oracle_worker, args=(world, port, str(tmp_path), gm, gh, b, iters), nprocs=world, join=True)
+    r = [torch.load(tmp_path / f"oracle_rank{k}.pt", weights_only=True) for k in range(world)]
+    cfg = small_cfg(preprocess_type="log_normalized", nb_critic=2)
+    nets, xm, xh, lm, lh = make_problem(gm, gh, world * b, cfg)
+    cm, ch = O.centroid_table(xm, lm, 12), O.centroid_table(xh, lh, 12)
+    rt = ReplicatedTrainer(nets, cfg, cm, ch, seeds=[100 + k for k in range(world)])
+    shards = [(xm[k * b:(k + 1) * b], xh[k * b:(k + 1) * b], lm[k * b:(k + 1) * b, None], lh[k * b:(k + 1) * b, None])
+              for k in range(world)]
+    exp = [rt.iteration(i, shards) for i in range(iters)]
+    floor = {"g_adv": 0.5, "g_loss": 0.5}
+    glob = ("g_loss", "g_adv", "cycle_loss", "celltype_loss", "fm_loss", "kl_loss")   # the same on every rank
+    for i in (0, 2):
+        tol = 1e-4 if i == 0 else 5e-3
+        for k in glob:
+            for rk in r:
+                assert rel(rk["res"][i][k], exp[i][k], floor.get(k, 0.0)) <= tol, (i, k, rk["res"][i][k], exp[i][k])
+        for k in ("d_m_loss", "d_h_loss", "fake_human_var"):                            # rank-local values
+            assert rel(r[0]["res"][i][k], exp[i][k], 0.5) <= tol, (i, k)
+    # every rank holds the oracle replicas' parameters
+    tr = rt.replicas[0]
+    for n in ("g_m2h", "g_h2m", "d_m", "d_h"):
+        for k, v in r[0]["sd"][n].items():
+            assert torch.equal(v, r[1]["sd"][n][k]) or k.endswith(("running_mean", "running_var")), (n, k)
+            if k.endswith(("num_batches_tracked", "running_mean", "running_var")) or O.is_gauge_param(k, r[0]["sd"][n]):
+                continue
+            ref, init = tr.nets[n][k].detach(), nets[n][k]
+            moved = (ref - init).abs()
+            if float(moved.max()) == 0.0:
+                continue
+            mask = moved > 0.5 * cfg["lr"]       # elements with a real gradient move by about lr per Adam step
+            if float(mask.float().mean()) < 0.5:
+                continue
+            assert update_rel_l2(v[mask], ref[mask], init[mask]) <= 3e-1, (n, k)
+
+
+def _bench_line(cmd, env, timeout):
     import json
     import subprocess
-    env = dict(os.environ, CGRNA_BENCH_BACKEND="gloo", CGRNA_BENCH_WATCHDOG="90")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", str(31600 + os.getpid() % 2000), os.path.join(ROOT, "bench.py"), "--gpus", "2",
-           "--steps", "4", "--warmup", "2", "--genes", "256", "--batch", "32"]
-    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=110)
-    assert p.returncode == 0, p.stderr[-2000:]
+    p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout
-    out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["steps"] == 4 and out["config"]["global_batch"] == 64
+    return json.loads(lines[0])
+
+
+def test_bench_with_two_ranks():
+    """bench.py launched the way the driver launches it for N > 1 (one process per rank under torch.distributed.run),
+    at the size the metric is quoted on (5000 genes, batch 512 per rank), with the two ranks sharing the test GPU
+    over gloo: the timed loop, the max over ranks, the GEMM timing pass that only rank 0 runs (it must not issue
+    collectives the other rank does not join) and the one JSON line."""
+    env = dict(os.environ, CGRNA_BENCH_BACKEND="gloo", CGRNA_BENCH_WATCHDOG="150")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(31600 + os.getpid() % 2000), os.path.join(ROOT, "bench.py"), "--gpus", "2",
+           "--steps", "8", "--warmup", "2", "--genes", "5000", "--batch", "512"]
+    out = _bench_line(cmd, env, 170)
+    assert out["n_gpus"] == 2 and out["steps"] == 8 and out["config"]["global_batch"] == 1024
     assert out["value"] > 0 and out["roofline"]["achieved"] > 0 and out["cpu_baseline"] is None
+
+
+def test_bench_starts_its_own_ranks():
+    """Plain `python bench.py --gpus 2` (no launcher, WORLD_SIZE unset) starts the two ranks itself and prints one
+    line for a two-rank job; a --gpus that contradicts the launcher's WORLD_SIZE is refused."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(CGRNA_BENCH_BACKEND="gloo", CGRNA_BENCH_WATCHDOG="100")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--genes", "256",
+           "--batch", "32"]
+    out = _bench_line(cmd, env, 120)
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 64 and out["config"]["parallelism"] == "dp2"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="1"),
+                       cwd=ROOT, capture_output=True, text=True, timeout=100)
+    assert p.returncode != 0 and "WORLD_SIZE" in p.stderr

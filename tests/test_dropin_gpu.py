@@ -95,6 +95,34 @@ def test_module_level_against_reference(tag):
         assert rel(bd[k].double(), ref.double()) <= 2e-4, k
 
 
+def test_double_differentiation_through_a_module_is_refused():
+    """The modules' hand-written backward passes are first-order only.  The reference's own penalty code,
+    torch.autograd.grad(d(x), x, create_graph=True) followed by .backward() (GAN_functions.py:199-203), must not run
+    through them with the second-order terms silently dropped: it raises, and compute_gradient_penalty is the
+    supported route (its gradients are checked against the reference in test_module_level_against_reference)."""
+    from cycle_gan_rna_amd import GAN_functions as F
+    from cycle_gan_rna_amd import cWGAN as W
+    from oracle import cyclegan_oracle as O
+    cfg = O.default_config(hidden_dims=[96, 64, 32], preprocess_type="log_normalized")
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    d = F.GeneExpressionDiscriminator(40, [12], cfg).to(dev)
+    g = F.GeneExpressionGenerator(40, 40, [12], cfg).to(dev)
+    x = torch.rand(16, 40, device=dev, requires_grad=True)
+    lab = torch.randint(0, 12, (16, 1), device=dev)
+    for fn in (lambda: d(x, lab), lambda: g(x, lab)[0]):
+        out = fn()
+        with pytest.raises(RuntimeError, match="first-order only"):
+            torch.autograd.grad(out, x, grad_outputs=torch.ones_like(out), create_graph=True)
+    wd = W.Discriminator(40, [12], 0).to(dev)          # the notebook's own penalty (cWGAN_my.ipynb cell 3) likewise
+    out = wd(x, lab, None)
+    with pytest.raises(RuntimeError, match="first-order only"):
+        torch.autograd.grad(out, x, grad_outputs=torch.ones_like(out), create_graph=True)
+    gp = F.compute_gradient_penalty(d, x.detach(), torch.rand(16, 40, device=dev), dev, lab)
+    gp.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for n, p in d.named_parameters() if "9.bias" not in n)
+
+
 class Obs:
     def __init__(self, names):
         import pandas as pd
@@ -106,19 +134,23 @@ class TwoCol:
         return np.asarray(x)[:, :2]
 
 
-@pytest.mark.parametrize("tag", ["one_iter_epochs", "cadence_linear", "counts"])
+@pytest.mark.parametrize("tag", ["one_iter_epochs", "cadence_linear", "counts", "unequal_restart"])
 def test_train_function_against_reference(tag):
+    """unequal_restart: the species have 40 and 88 cells - the shorter loader is restarted and re-shuffled within
+    every epoch and ragged batches are truncated to the smaller of the pair (GAN_functions.py:299-319)."""
     from sklearn.decomposition import PCA
     from sklearn.preprocessing import StandardScaler
     from cycle_gan_rna_amd import GAN_functions as F
     from oracle import cyclegan_oracle as O
-    fx = torch.load(os.path.join(GOLD, "function_level.pt"), weights_only=True)[tag]
+    fx = torch.load(os.path.join(GOLD, "function_level_unequal.pt" if tag == "unequal_restart" else "function_level.pt"),
+                    weights_only=True)[tag]
     cfg = dict(fx["cfg"], device="cuda", noise="host_replay", progress=False)
     gm, gh, N = fx["g_mouse"], fx["g_human"], fx["N"]
+    nm, nh = (N, N) if isinstance(N, int) else N
     mods = build_modules(gm, gh, cfg, fx["init_seed"])
-    xm, _ = O.synthetic_expression(N, gm, 12, seed=fx["data_seed"])
-    xh, _ = O.synthetic_expression(N, gh, 12, seed=fx["data_seed"] + 1)
-    lm, lh = O.balanced_labels(N, 12, fx["data_seed"] + 2), O.balanced_labels(N, 12, fx["data_seed"] + 3)
+    xm, _ = O.synthetic_expression(nm, gm, 12, seed=fx["data_seed"])
+    xh, _ = O.synthetic_expression(nh, gh, 12, seed=fx["data_seed"] + 1)
+    lm, lh = O.balanced_labels(nm, 12, fx["data_seed"] + 2), O.balanced_labels(nh, 12, fx["data_seed"] + 3)
     names = [f"type{i:02d}" for i in range(12)]
     idx_to_ct = dict(enumerate(names))
     cat = np.concatenate([lm.numpy(), lh.numpy()])[:, None]
@@ -155,7 +187,7 @@ def test_train_function_against_reference(tag):
     assert float((got - ref_final["values"].double()).norm() / upd_ref.norm()) <= 0.35
 
 
-@pytest.mark.parametrize("identity,iters_per_epoch", [(False, 1), (True, 1), (False, 7)])
+@pytest.mark.parametrize("identity,iters_per_epoch", [(False, 1), (True, 1), (False, 7), (False, (3.25, 6.25))])
 def test_train_function_default_mode_replays_graphs(identity, iters_per_epoch):
     """Default mode of the drop-in loop (noise drawn in HBM): the step runs as HIP graphs on several streams.  With
     the same seed, a run that launches every kernel eagerly on one stream gives the same metrics bit for bit.
@@ -164,12 +196,15 @@ def test_train_function_default_mode_replays_graphs(identity, iters_per_epoch):
     from oracle import cyclegan_oracle as O
     fx = torch.load(os.path.join(GOLD, "function_level.pt"), weights_only=True)["one_iter_epochs"]
     gm, gh, N = fx["g_mouse"], fx["g_human"], fx["N"]
-    N *= iters_per_epoch        # several iterations per epoch: generator forwards are issued ahead, across batches
+    # several iterations per epoch: generator forwards are issued ahead, across batches; a pair of factors: the two
+    # species differ in size, so one loader restarts within the epoch and the last batches are ragged
+    fm_, fh_ = iters_per_epoch if isinstance(iters_per_epoch, tuple) else (iters_per_epoch, iters_per_epoch)
+    nm, nh = int(N * fm_), int(N * fh_)
     if identity:
         gh = gm
-    xm, _ = O.synthetic_expression(N, gm, 12, seed=3)
-    xh, _ = O.synthetic_expression(N, gh, 12, seed=4)
-    lm, lh = O.balanced_labels(N, 12, 5), O.balanced_labels(N, 12, 6)
+    xm, _ = O.synthetic_expression(nm, gm, 12, seed=3)
+    xh, _ = O.synthetic_expression(nh, gh, 12, seed=4)
+    lm, lh = O.balanced_labels(nm, 12, 5), O.balanced_labels(nh, 12, 6)
     names = [f"type{i:02d}" for i in range(12)]
     cat = np.concatenate([lm.numpy(), lh.numpy()])[:, None]
     res = {}

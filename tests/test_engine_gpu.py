@@ -177,6 +177,67 @@ def test_default_hidden_dims_one_iteration(ops):
         assert rel(got[1][k], exp[1][k], FLOOR.get(k, 0.0)) <= 2e-3, (k, got[1][k], exp[1][k])
 
 
+@pytest.mark.parametrize("genes,precision", [(5000, "fp32"), (5000, "bf16"), (20000, "fp32")])
+def test_full_size_iteration_matches_oracle(genes, precision):
+    """The sizes the throughput is quoted on - 5000 genes per species with batch 512 (float32 and bf16 MFMA) and
+    20 000 genes with batch 512 per GPU - where the tuned tile / split-K table and the cost model decide every
+    product: one critic step + one generator step against the CPU oracle on the same weights, batch and noise.
+    Losses to the stated tolerances (float32 1e-4, bf16 2e-2); generated cells to 1e-4 of the largest value in
+    float32 and 1.5e-1 mean absolute deviation in bf16 (see test_bf16_mfma_path_within_stated_tolerance).
+    Gradients, float32 only, tensor by tensor with the float64 oracle as the arbiter: relative L2 error at most
+    1e-4, or at most twice the error the float32 CPU oracle itself makes against float64.  (The generator
+    gradients all carry the factor 1/|moving average of g_adv|, GAN_functions.py:387, and g_adv is a difference of
+    critic outputs that nearly cancel, so in float32 they are uncertain to 1e-2 as a whole - for the CPU oracle
+    as much as for the device.)"""
+    from cycle_gan_rna_amd.engine import StepEngine
+    from cycle_gan_rna_amd.noise import HostReplayNoise
+    from cycle_gan_rna_amd.ops import HipOps
+    from tests.helpers import oracle_iteration_grads
+    cfg = O.default_config(preprocess_type="log_normalized", nb_critic=4)
+    B = 512
+    nets, xm, xh, lm, lh = make_problem(genes, genes, B, cfg)
+    lm2, lh2 = lm[:, None], lh[:, None]
+    cm, ch = O.centroid_table(xm, lm, 12), O.centroid_table(xh, lh, 12)
+    exp, g32 = oracle_iteration_grads(nets, cfg, cm, ch, xm, xh, lm2, lh2, torch.float32, seed=11)
+    eng = StepEngine(nets, cfg, cm, ch, HipOps("cuda:0", precision=precision), B)
+    grabbed, real_adam = {}, eng._adam
+
+    def adam(arena):
+        grabbed["d" if arena is eng.arena_d else "g"] = arena.g.clone()
+        real_adam(arena)
+    eng._adam = adam
+    torch.manual_seed(11)
+    got = eng.iteration(0, xm.cuda(), xh.cuda(), lm2.cuda(), lh2.cuda(), HostReplayNoise("cuda:0"))
+    torch.cuda.synchronize()
+    tol = 1e-4 if precision == "fp32" else 2e-2
+    for k in LOSS_KEYS:
+        assert rel(got[k], exp[k], FLOOR.get(k, 0.0)) <= tol, (k, got[k], exp[k])
+    for side, dev_t in (("fake_human", eng.fake_human), ("fake_mouse", eng.fake_mouse)):
+        if precision == "fp32":
+            assert rel(dev_t, exp[side]) <= 1e-4, (side, rel(dev_t, exp[side]))
+        else:
+            d = (dev_t.cpu().double() - exp[side].double()).abs().mean() / exp[side].double().abs().mean()
+            assert float(d) <= 1.5e-1, (side, float(d))
+    if precision != "fp32":
+        return
+    _, g64 = oracle_iteration_grads(nets, cfg, cm, ch, xm, xh, lm2, lh2, torch.float64, seed=11)
+    checked = 0
+    for which, arena in (("d", eng.arena_d), ("g", eng.arena_g)):
+        flat = grabbed[which].cpu()
+        for (n, k), (off, cnt, _) in arena.offsets.items():
+            if (n, k) not in g64 or O.is_gauge_param(k, nets[n]):
+                continue
+            ref = g64[(n, k)].reshape(-1)
+            den = float(ref.norm())
+            if den == 0.0:
+                continue
+            e_hip = float((flat[off:off + cnt].double() - ref).norm()) / den
+            e_cpu = float((g32[(n, k)].reshape(-1).double() - ref).norm()) / den
+            assert e_hip <= max(1e-4, 2.0 * e_cpu), (n, k, e_hip, e_cpu)
+            checked += 1
+    assert checked > 150
+
+
 def test_ragged_batch_smaller_than_workspace(ops):
     """A last batch smaller than the workspace (GAN_functions.py:315-319)."""
     from cycle_gan_rna_amd.engine import StepEngine

@@ -64,15 +64,18 @@ def test_module_level(tag):
         assert rel(got, spec["values"], floor) <= 0.5, k
 
 
-@pytest.mark.parametrize("tag", ["one_iter_epochs", "cadence_linear"])
+@pytest.mark.parametrize("tag", ["one_iter_epochs", "cadence_linear", "unequal_restart"])
 def test_function_level(tag):
-    fx = load("function_level.pt")[tag]
+    """unequal_restart: 40 mouse and 88 human cells, so the mouse loader is restarted and re-shuffled in the middle
+    of every epoch and ragged last batches are truncated to the smaller of the pair (GAN_functions.py:299-319)."""
+    fx = load("function_level_unequal.pt" if tag == "unequal_restart" else "function_level.pt")[tag]
     cfg = dict(fx["cfg"])
     gm, gh, N = fx["g_mouse"], fx["g_human"], fx["N"]
+    nm, nh = (N, N) if isinstance(N, int) else N
     nets = init_params.build_nets(gm, gh, [12], cfg, fx["init_seed"])
-    xm, _ = O.synthetic_expression(N, gm, 12, seed=fx["data_seed"])
-    xh, _ = O.synthetic_expression(N, gh, 12, seed=fx["data_seed"] + 1)
-    lm, lh = O.balanced_labels(N, 12, fx["data_seed"] + 2), O.balanced_labels(N, 12, fx["data_seed"] + 3)
+    xm, _ = O.synthetic_expression(nm, gm, 12, seed=fx["data_seed"])
+    xh, _ = O.synthetic_expression(nh, gh, 12, seed=fx["data_seed"] + 1)
+    lm, lh = O.balanced_labels(nm, 12, fx["data_seed"] + 2), O.balanced_labels(nh, 12, fx["data_seed"] + 3)
     tr = O.OracleTrainer(nets, cfg, O.centroid_table(xm, lm, 12), O.centroid_table(xh, lh, 12))
     torch.manual_seed(fx["train_seed"])
     metrics = oracle_train(tr, xm, xh, lm[:, None], lh[:, None], cfg)
