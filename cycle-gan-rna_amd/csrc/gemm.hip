@@ -56,7 +56,10 @@ struct GemmArgs {
   unsigned a_bytes, b_bytes;   // footprints of A and B in memory (hardware range check of the buffer loads)
 };
 
-constexpr int BK = 32;
+#ifndef CG_BK
+#define CG_BK 32
+#endif
+constexpr int BK = CG_BK;
 
 // Slabs of global loads kept in flight ahead of the MFMAs, per block tile (register stages).
 constexpr int prefetch_depth(int bm, int bn) { return bm * bn <= 64 * 64 ? CG_PF_SMALL : (bm * bn <= 128 * 64 ? CG_PF_MID : CG_PF_BIG); }
@@ -178,10 +181,8 @@ __device__ __forceinline__ void tile_coords(int tile, int tiles_m, int tiles_n, 
 
 // ------------------------------------------------------------------------------------------------
 // bf16 path: float32 operands in memory, rounded to bf16 while they are staged into LDS, multiplied
-// with v_mfma_f32_16x16x32_bf16 (float32 accumulate).  Both operand kinds end up in LDS as
-// [row][k] bf16 with k contiguous (row stride 80 elements = 160 B: conflict-free ds_read_b128), so
-// one fragment read serves a whole 32-deep MFMA; m-major operands are transposed in registers
-// (4k x 4row micro-tiles) on their way in.  BKH = 64 per slab, double-buffered.
+// with v_mfma_f32_16x16x32_bf16 (float32 accumulate).  BKH = 64 per slab, double-buffered; the LDS
+// images of the two operand kinds are described at lds_elems() below.
 // ------------------------------------------------------------------------------------------------
 constexpr int BKH = 64;
 constexpr int LDH = BKH + 16;   // LDS row stride in bf16 elements
@@ -380,6 +381,67 @@ __global__ void __launch_bounds__(256 * KW) gemm_bf16_kernel(GemmArgs g) {
     }
 }
 
+// Tail of the float32 kernels: the wave groups' accumulators are added through LDS in group order (the caller's K
+// loop has ended on a barrier and nothing else touches LDS any more), then either the raw partial sums go to this
+// split's slab or the epilogue is applied.  32x32 accumulator: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+template <int TM, int TN, int KW>
+__device__ __forceinline__ void finish_f32(const GemmArgs& g, f32x16 (&acc)[TM][TN], float* smem, int bm, int bn, int wm,
+                                           int wn, int lane, int wave, int kg) {
+  const int li = lane & 31, lh = lane >> 5;
+  if (KW > 1) {
+    float* xs = smem + ((kg > 0 ? kg - 1 : 0) * 4 + wave) * (TM * TN * 16 * 64) + lane;
+    if (kg > 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) xs[((i * TN + j) * 16 + r) * 64] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (kg > 0) return;
+#pragma unroll
+    for (int q = 1; q < KW; ++q)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            acc[i][j][r] += xs[(q - 1) * 4 * (TM * TN * 16 * 64) + ((i * TN + j) * 16 + r) * 64];
+  }
+  if (gridDim.y > 1) {   // split-K: raw partial sums, combined by splitk_reduce_kernel or by the consumer
+    float* wsp = g.ws + (size_t)blockIdx.y * g.M * g.N;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = bn + wn + 32 * j + li;
+        if (col >= g.N) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = bm + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (row < g.M) wsp[(size_t)row * g.N + col] = acc[i][j][r];
+        }
+      }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = bn + wn + 32 * j + li;
+      if (col >= g.N) continue;
+      const float bv = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = bm + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row >= g.M) continue;
+        epilogue_store(g, row, col, acc[i][j][r] + bv);
+      }
+    }
+}
+
 // KW wave groups of four waves share a block tile: every group multiplies its own 1/KW of each K slab into its own
 // accumulators (two or more waves per SIMD hide each other's LDS and barrier waits even when the workgroup has
 // the CU to itself); the groups' accumulators are added through LDS, in group order, before the epilogue.
@@ -485,60 +547,212 @@ __global__ void __launch_bounds__(256 * KW) gemm_f32_kernel(GemmArgs g) {
     }
   }
 
-  if (KW > 1) {   // add the wave groups' accumulators through LDS (the K loop ended on a barrier)
-    float* xs = smem + ((kg > 0 ? kg - 1 : 0) * 4 + wave) * (TM * TN * 16 * 64) + lane;
-    if (kg > 0) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) xs[((i * TN + j) * 16 + r) * 64] = acc[i][j][r];
-    }
-    __syncthreads();
-    if (kg > 0) return;
-#pragma unroll
-    for (int q = 1; q < KW; ++q)
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            acc[i][j][r] += xs[(q - 1) * 4 * (TM * TN * 16 * 64) + ((i * TN + j) * 16 + r) * 64];
-  }
+  finish_f32<TM, TN, KW>(g, acc, smem, bm, bn, wm, wn, lane, wave, kg);
+}
 
-  // epilogue: 32x32 accumulator, col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  if (gridDim.y > 1) {   // split-K: raw partial sums, combined by splitk_reduce_kernel
-    float* wsp = g.ws + (size_t)blockIdx.y * g.M * g.N;
+// ------------------------------------------------------------------------------------------------
+// float32 kernel whose operand tiles come in by LDS-DMA (buffer_load_dwordx4 ... lds): no staging registers, no
+// ds_write pass, and S - 1 K slabs in flight behind a counted s_waitcnt, so a workgroup that has a CU to itself (the
+// usual case at batch 512) covers the load latency itself.  One raw s_barrier per slab (never __syncthreads(), whose
+// fence would drain the loads in flight).  An LDS-DMA instruction writes the wave's 64 x 16 bytes
+// contiguously, so the LDS images are unpadded and lane-linear:
+//   k-major operand  [row][BK]: a row is 8 pieces of 16 bytes; slot (row, c) holds the piece q = c ^ ((row >> 1) & 7)
+//                    of that row (the permutation is applied to the SOURCE address; the fragment read applies the
+//                    same one), which spreads the 16 rows of a ds_read_b128 lane group over all 64 banks
+//   m-major operand  [k][ROWS]: a piece is 4 consecutive rows at one k; fragments are ds_read_b32 along the rows
+// Conditions (checked by the host): both operands 16-byte aligned with leading dimensions a multiple of 4 floats; the
+// contiguous extent of each operand (K when k-major, its row count when m-major) a multiple of 4, so a piece is
+// inside the matrix or outside it as a whole.  Pieces outside are requested at an out-of-range offset; the range
+// check makes them zeros in LDS.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int ROWS, bool MMAJ, int NT>
+struct DmaTile {
+  static constexpr int R = ROWS * BK / 4 / NT;   // 16-byte pieces per thread and slab
+  static_assert(R >= 1 && R * NT * 4 == ROWS * BK, "tile does not divide over the workgroup");
+  unsigned off[R];   // byte offset of the piece in the slab to be issued next
+  int kk[R];         // k of the piece inside a slab (1 << 30: the piece's rows are outside the matrix)
+  unsigned step;     // advance per slab in bytes
+
+  __device__ __forceinline__ void init(int t, int ld, int row0, int nrows, int k0) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int col = bn + wn + 32 * j + li;
-        if (col >= g.N) continue;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = bm + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (row < g.M) wsp[(size_t)row * g.N + col] = acc[i][j][r];
-        }
+    for (int j = 0; j < R; ++j) {
+      const int p = t + NT * j;
+      if (!MMAJ) {
+        const int row = p >> 3, q = (p & 7) ^ ((row >> 1) & 7), r = row0 + row;
+        kk[j] = r < nrows ? 4 * q : (1 << 30);
+        off[j] = ((unsigned)r * ld + k0 + 4 * q) * 4u;
+      } else {
+        const int k = p / (ROWS / 4), r = row0 + 4 * (p % (ROWS / 4));
+        kk[j] = r < nrows ? k : (1 << 30);
+        off[j] = ((unsigned)(k0 + k) * ld + r) * 4u;
       }
-    return;
+    }
+    step = (MMAJ ? (unsigned)BK * ld : (unsigned)BK) * 4u;
   }
+  // Issue the next slab into `dst` (this operand's image in an LDS stage); kleft = k values of the product that
+  // remain from the slab's first k on (<= 0: the whole slab is outside, every piece reads as zeros).  lwave: index
+  // of the issuing wave in the workgroup.
+  __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t rs, float* dst, int lwave, int kleft) {
+#if defined(CG_ABL) && (CG_ABL & 1)     // timing-only build: no operand traffic
+    return;
+#endif
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + (j * NT + lwave * 64) * 4), 16,
+                                               kk[j] < kleft ? off[j] : OOB_OFF, 0, 0, 0);
+      off[j] += step;
+    }
+  }
+};
+
+// Every wave issues its share of the next slab's LDS-DMA loads right after the barrier that frees a stage.  (Tried and
+// dropped: dedicated loader waves beside the computing waves, so that no computing wave ever issues a memory
+// instruction in the K loop.  512 x 2048 x 5000 on 64 x 64 tiles: 135 us with one loader wave per workgroup - one wave
+// cannot issue the slab's 16 pieces in a slab's time -, 127 us with two, 113 us with four, 109 us without any.)
+template <int BM, int BN, bool TA, bool TB, int KW, int S>
+__global__ void __launch_bounds__(256 * KW) gemm_f32_dma_kernel(GemmArgs g) {
+  constexpr int NC = 256 * KW;
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr bool A_MMAJ = TA, B_MMAJ = !TB;
+  constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK, STAGE = A_ELEMS + B_ELEMS;
+  static_assert(S >= 3, "needs at least three LDS stages");
+  static_assert(KW == 1 || TM * TN * 16 * 256 * (KW - 1) <= S * STAGE, "accumulator exchange does not fit in LDS");
+  __shared__ __align__(16) float smem[S * STAGE];      // the kernel's only LDS object
+
+  const int tile = xcd_tile();
+  int tile_m, tile_n;
+  tile_coords(tile, (g.M + BM - 1) / BM, g.tiles_n, tile_m, tile_n);
+  const int bm = tile_m * BM, bn = tile_n * BN;
+  const int nk_all = (g.K + BK - 1) / BK;
+  const int kt0 = blockIdx.y * g.kt_per_split;
+  const int nk = min(nk_all, kt0 + g.kt_per_split);
+  const int nslab = nk - kt0;
+  typedef DmaTile<BM, A_MMAJ, NC> TileA;
+  typedef DmaTile<BN, B_MMAJ, NC> TileB;
+  constexpr int LPS = TileA::R + TileB::R;   // LDS-DMA instructions per wave and slab
+  static_assert((S - 1) * LPS <= 63, "more loads in flight than s_waitcnt vmcnt can count");
+  const __amdgpu_buffer_rsrc_t rsA = make_rsrc(g.A, g.a_bytes), rsB = make_rsrc(g.B, g.b_bytes);
+  int kleft = min(g.K, nk * BK) - kt0 * BK;      // k values this split still has to bring in
+  const int lwave = threadIdx.x >> 6;
+  TileA da;
+  TileB db;
+  da.init(threadIdx.x, g.lda, bm, g.M, kt0 * BK);
+  db.init(threadIdx.x, g.ldb, bn, g.N, kt0 * BK);
+
+  const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3, kg = threadIdx.x >> 8;
+  const int wm = (wave >> 1) * (BM / 2), wn = (wave & 1) * (BN / 2);
+  const int li = lane & 31, lh = lane >> 5;
+  constexpr int CG = BK / 8 / KW;   // groups of eight k per slab handled by one wave group
+  static_assert(CG * KW * 8 == BK, "K slab does not divide over the wave groups");
+  static_assert(CG % 2 == 0, "the fragment double buffer needs an even number of k groups per slab and wave group");
+
+  f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = bn + wn + 32 * j + li;
-      if (col >= g.N) continue;
-      const float bv = g.bias ? g.bias[col] : 0.f;
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = bm + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row >= g.M) continue;
-        epilogue_store(g, row, col, acc[i][j][r] + bv);
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // Fragments of one group of eight k (TM + TN ds_read_b128 for k-major operands) and its 4 * TM * TN MFMAs.
+  const int swz = (li >> 1) & 7;
+  auto load_frag = [&](float (&a)[TM][4], float (&b)[TN][4], const float* As, int c) {
+#if defined(CG_ABL) && (CG_ABL & 4)     // timing-only build without fragment reads
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) asm volatile("" : "=v"(a[i][q]));
+#pragma unroll
+      for (int jj = 0; jj < TN; ++jj) asm volatile("" : "=v"(b[jj][q]));
+    }
+    return;
+#endif
+    const float* Bs = As + A_ELEMS;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      if (!A_MMAJ) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(As + (wm + 32 * i + li) * BK + 4 * ((2 * c + lh) ^ swz));
+        a[i][0] = t[0]; a[i][1] = t[1]; a[i][2] = t[2]; a[i][3] = t[3];
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[i][q] = As[(8 * c + 4 * lh + q) * BM + wm + 32 * i + li];
       }
     }
+#pragma unroll
+    for (int jj = 0; jj < TN; ++jj) {
+      if (!B_MMAJ) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(Bs + (wn + 32 * jj + li) * BK + 4 * ((2 * c + lh) ^ swz));
+        b[jj][0] = t[0]; b[jj][1] = t[1]; b[jj][2] = t[2]; b[jj][3] = t[3];
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b[jj][q] = Bs[(8 * c + 4 * lh + q) * BN + wn + 32 * jj + li];
+      }
+    }
+  };
+  auto mfma_group = [&](const float (&a)[TM][4], const float (&b)[TN][4]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int jj = 0; jj < TN; ++jj)
+          acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[jj][q], acc[i][jj], 0, 0, 0);
+  };
+
+  // Stage j % S holds slab j.  All S stages are filled up front; when every wave has read slab j (the barrier that
+  // also publishes slab j + 1) its stage is refilled with slab j + S, so S - 1 slabs are in flight behind the compute.
+  // The fragments of a slab's first k group are read right after the barrier that publishes it, while the MFMAs of
+  // the previous slab's last group are still to be issued: the matrix pipe has work across the barrier.
+#pragma unroll
+  for (int s = 0; s < S; ++s) {
+    da.issue(rsA, smem + s * STAGE, lwave, kleft);
+    db.issue(rsB, smem + s * STAGE + A_ELEMS, lwave, kleft);
+    kleft -= BK;
+  }
+  float fa[2][TM][4], fb[2][TN][4];
+  wait_vmcnt<(S - 1) * LPS>();          // slab 0 has landed for this wave ...
+  __builtin_amdgcn_s_barrier();         // ... and for every wave
+  load_frag(fa[0], fb[0], smem, kg * CG);
+  int st_cur = 0;
+  for (int j = 0; j < nslab; ++j) {
+    const float* As = smem + st_cur * STAGE;
+    const int st_next = st_cur + 1 == S ? 0 : st_cur + 1;
+#pragma unroll
+    for (int cc = 0; cc < CG; ++cc) {
+      if (cc + 1 < CG) {
+        load_frag(fa[(cc + 1) & 1], fb[(cc + 1) & 1], As, kg * CG + cc + 1);
+      } else {
+        // every read of slab j has been issued; once they are retired and all waves are here, slab j + 1 (landed for
+        // this wave when all but the S - 2 youngest slabs' loads are done) is visible and stage st_cur is free
+#if !(defined(CG_ABL) && (CG_ABL & 2))    // timing-only build without the per-slab barrier
+        wait_vmcnt<(S - 2) * LPS>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#endif
+        da.issue(rsA, smem + st_cur * STAGE, lwave, kleft);
+        db.issue(rsB, smem + st_cur * STAGE + A_ELEMS, lwave, kleft);
+        kleft -= BK;
+        load_frag(fa[0], fb[0], smem + st_next * STAGE, kg * CG);
+      }
+      // keep the reads of the next group ahead of this group's MFMAs (left alone, the compiler sinks them behind
+      // the MFMAs to save registers, and every group then starts by waiting for its own reads)
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_group(fa[cc & 1], fb[cc & 1]);
+    }
+    st_cur = st_next;
+  }
+  // the loads still in flight are out-of-range ones (they write zeros into LDS): retire them before LDS is reused
+  wait_vmcnt<0>();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  finish_f32<TM, TN, KW>(g, acc, smem, bm, bn, wm, wn, lane, wave, kg);
 }
 
 // Combine the split-K partials in split order and apply the epilogue of cg_gemm.  VEC4: four consecutive columns
@@ -669,6 +883,16 @@ bool launch_small(const GemmArgs& g, int transA, int transB, hipStream_t st) {
   return false;
 }
 
+void launch_splitk_reduce(const GemmArgs& g, int splits, hipStream_t st) {
+  const size_t total = (size_t)g.M * g.N;
+  auto al = [](const void* p, int ld) { return p == nullptr || (((uintptr_t)p % 16 == 0) && ld % 4 == 0); };
+  const bool v4 = g.N % 4 == 0 && al(g.C, g.ldc) && al(g.E, g.lde) && al(g.aux, g.ldaux) && al(g.ws, 4);
+  int blocks = (int)((total / (v4 ? 4 : 1) + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  if (v4) hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(blocks), dim3(256), 0, st, g, splits);
+  else hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(blocks), dim3(256), 0, st, g, splits);
+}
+
 template <int BM, int BN, bool HALF = false>
 int launch_f32(const GemmArgs& g, int transA, int transB, bool vec, hipStream_t st, int splits = 1) {
   GemmArgs a = g;
@@ -695,15 +919,47 @@ int launch_f32(const GemmArgs& g, int transA, int transB, bool vec, hipStream_t 
   else if (transA && !transB) CG_LAUNCH(true, false);
   else CG_LAUNCH(true, true);
 #undef CG_LAUNCH
-  if (splits > 1) {
-    const size_t total = (size_t)g.M * g.N;
-    auto al = [](const void* p, int ld) { return p == nullptr || (((uintptr_t)p % 16 == 0) && ld % 4 == 0); };
-    const bool v4 = g.N % 4 == 0 && al(g.C, g.ldc) && al(g.E, g.lde) && al(g.aux, g.ldaux) && al(g.ws, 4);
-    int blocks = (int)((total / (v4 ? 4 : 1) + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    if (v4) hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(blocks), dim3(256), 0, st, g, splits);
-    else hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(blocks), dim3(256), 0, st, g, splits);
-  }
+  if (splits > 1) launch_splitk_reduce(g, splits, st);
+  return cg_launch_status();
+}
+
+#ifndef CG_DKW_SMALL
+#define CG_DKW_SMALL 2
+#define CG_DKW_MID 2
+#define CG_DKW_BIG 2
+#endif
+#ifndef CG_DMA_STAGES
+#define CG_DMA_STAGES 3
+#endif
+constexpr int kwaves_dma(int bm, int bn) { return bm * bn <= 64 * 64 ? CG_DKW_SMALL : (bm * bn <= 128 * 64 ? CG_DKW_MID : CG_DKW_BIG); }
+
+// every variant is instantiated explicitly: launched only from inside the function template below, some of them
+// were left without a host-side launch stub by this compiler
+#define CG_DMA_INST(BM, BN)                                                                                              \
+  template __global__ void gemm_f32_dma_kernel<BM, BN, false, true, kwaves_dma(BM, BN), CG_DMA_STAGES>(GemmArgs);   \
+  template __global__ void gemm_f32_dma_kernel<BM, BN, false, false, kwaves_dma(BM, BN), CG_DMA_STAGES>(GemmArgs);  \
+  template __global__ void gemm_f32_dma_kernel<BM, BN, true, false, kwaves_dma(BM, BN), CG_DMA_STAGES>(GemmArgs);   \
+  template __global__ void gemm_f32_dma_kernel<BM, BN, true, true, kwaves_dma(BM, BN), CG_DMA_STAGES>(GemmArgs);
+CG_DMA_INST(128, 128)
+CG_DMA_INST(128, 64)
+CG_DMA_INST(64, 64)
+#undef CG_DMA_INST
+
+template <int BM, int BN>
+int launch_f32_dma(const GemmArgs& g, int transA, int transB, hipStream_t st, int splits) {
+  GemmArgs a = g;
+  const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
+  a.tiles_n = tn;
+  const int nk = (g.K + BK - 1) / BK;
+  a.kt_per_split = (nk + splits - 1) / splits;
+  splits = (nk + a.kt_per_split - 1) / a.kt_per_split;   // no empty split
+  constexpr int KW = kwaves_dma(BM, BN), S = CG_DMA_STAGES;
+  dim3 grid(tm * tn, splits), block(256 * KW);
+  if (!transA && transB) hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, false, true, KW, S>), grid, block, 0, st, a);
+  else if (!transA && !transB) hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, false, false, KW, S>), grid, block, 0, st, a);
+  else if (transA && !transB) hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, true, false, KW, S>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, true, true, KW, S>), grid, block, 0, st, a);
+  if (splits > 1) launch_splitk_reduce(g, splits, st);
   return cg_launch_status();
 }
 
@@ -715,6 +971,7 @@ extern "C" int cg_gemm(float* C, int ldc, const void* A, int lda, const void* B,
                        float slope, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
   if (!C || !A || !B || M < 0 || N < 0 || K < 0) return CG_ERR_BAD_ARG;
   if (M == 0 || N == 0) return CG_OK;
+  if (K == 0) return CG_ERR_BAD_ARG;      // an empty sum has no tile to launch; callers never need it
   if (epi < CG_EPI_NONE || epi > CG_EPI_MUL) return CG_ERR_BAD_ARG;
   if (epi == CG_EPI_MUL && !E) return CG_ERR_BAD_ARG;
   if (epi != CG_EPI_NONE && accumulate) return CG_ERR_BAD_ARG;
@@ -726,12 +983,12 @@ extern "C" int cg_gemm(float* C, int ldc, const void* A, int lda, const void* B,
   if (dtype != CG_F32 && dtype != CG_BF16) return CG_ERR_UNSUPPORTED;
   const bool half = dtype == CG_BF16;
   hipStream_t st = (hipStream_t)stream;
-  const size_t a_bytes = K ? ((size_t)(a_rows - 1) * lda + a_cols) * sizeof(float) : 0;
-  const size_t b_bytes = K ? ((size_t)(b_rows - 1) * ldb + b_cols) * sizeof(float) : 0;
+  const size_t a_bytes = ((size_t)(a_rows - 1) * lda + a_cols) * sizeof(float);
+  const size_t b_bytes = ((size_t)(b_rows - 1) * ldb + b_cols) * sizeof(float);
   if (a_bytes >= OOB_OFF || b_bytes >= OOB_OFF) return CG_ERR_UNSUPPORTED;   // 32-bit buffer offsets
   GemmArgs g{(const float*)A, (const float*)B, C, bias, E, aux, M, N, K, lda, ldb, ldc, lde, ldaux,
              epi, accumulate, slope, 0, 1 << 30, (float*)workspace, (unsigned)a_bytes, (unsigned)b_bytes};
-  if (K > 0 && (K <= 16 || N <= 2) && launch_small(g, transA, transB, st)) return cg_launch_status();
+  if ((K <= 16 || N <= 2) && launch_small(g, transA, transB, st)) return cg_launch_status();
   const bool vec = (((uintptr_t)A | (uintptr_t)B) % 16 == 0) && (lda % 4 == 0) && (ldb % 4 == 0);
   // Tile and split-K choice by a cost model fitted to a sweep of the step's shapes on MI355X (microseconds).
   // A workgroup alone on a CU needs L per K slab (latency-bound); n workgroups sharing a CU overlap and finish a
@@ -747,8 +1004,11 @@ extern "C" int cg_gemm(float* C, int ldc, const void* A, int lda, const void* B,
   static const int split_choices[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
   int best = 2, best_splits = 1;
   double best_cost = 1e300;
+  // tuning aids (tools/): read from the environment on every call only when CGRNA_GEMM_TUNING was set at the first call
+  static const bool tuning = getenv("CGRNA_GEMM_TUNING") != nullptr;
   double tile_bias[3] = {1.0, 1.0, 1.0};
-  if (const char* f = getenv("CGRNA_GEMM_BIAS")) sscanf(f, "%lf,%lf,%lf", &tile_bias[0], &tile_bias[1], &tile_bias[2]);
+  if (tuning)
+    if (const char* f = getenv("CGRNA_GEMM_BIAS")) sscanf(f, "%lf,%lf,%lf", &tile_bias[0], &tile_bias[1], &tile_bias[2]);
   for (int c = 0; c < 3; ++c) {
     const long tiles = (long)((M + cands[c].bm - 1) / cands[c].bm) * ((N + cands[c].bn - 1) / cands[c].bn);
     for (int sp : split_choices) {
@@ -763,7 +1023,7 @@ extern "C" int cg_gemm(float* C, int ldc, const void* A, int lda, const void* B,
     }
   }
   if (workspace) {      // shapes that were swept on the device: take the measured best
-    static const bool use_table = getenv("CGRNA_GEMM_NO_TABLE") == nullptr;
+    const bool use_table = !tuning || getenv("CGRNA_GEMM_NO_TABLE") == nullptr;
     const TunedGemm* tab = half ? tuned_bf16 : tuned_f32;
     const size_t ntab = half ? sizeof(tuned_bf16) / sizeof(TunedGemm) : sizeof(tuned_f32) / sizeof(TunedGemm);
     for (size_t i = 0; use_table && i < ntab; ++i) {
@@ -776,7 +1036,7 @@ extern "C" int cg_gemm(float* C, int ldc, const void* A, int lda, const void* B,
       }
     }
   }
-  if (const char* f = getenv("CGRNA_GEMM_OVERRIDE")) {   // tuning aid: "M,N,K,transA,transB,accumulate,tile,splits" for one shape
+  if (const char* f = tuning ? getenv("CGRNA_GEMM_OVERRIDE") : nullptr) {   // tuning aid: "M,N,K,transA,transB,accumulate,tile,splits" for one shape
     int m, n, k, ta, tb, ac, t = 0, sp = 1;
     if (sscanf(f, "%d,%d,%d,%d,%d,%d,%d,%d", &m, &n, &k, &ta, &tb, &ac, &t, &sp) == 8 && m == M && n == N && k == K &&
         ta == transA && tb == transB && ac == accumulate && t >= 0 && t < 3 && sp >= 1 &&
@@ -785,12 +1045,20 @@ extern "C" int cg_gemm(float* C, int ldc, const void* A, int lda, const void* B,
       best_splits = sp;
     }
   }
-  if (const char* f = getenv("CGRNA_GEMM_FORCE")) {   // tuning aid: "tile,splits" with tile 0=128x128 1=128x64 2=64x64
+  if (const char* f = tuning ? getenv("CGRNA_GEMM_FORCE") : nullptr) {   // tuning aid: "tile,splits" with tile 0=128x128 1=128x64 2=64x64
     int t = 0, sp = 1;
     if (sscanf(f, "%d,%d", &t, &sp) == 2 && t >= 0 && t < 3 && sp >= 1 && (sp == 1 || (workspace && (size_t)sp * per <= workspace_bytes))) {
       best = t;
       best_splits = sp;
     }
+  }
+  // LDS-DMA staging needs every 16-byte piece of a tile to lie inside the matrix or outside it as a whole
+  const bool dma = !half && vec && (transA ? M % 4 == 0 : K % 4 == 0) && (transB ? K % 4 == 0 : N % 4 == 0) &&
+                   !(tuning && getenv("CGRNA_GEMM_NO_DMA"));
+  if (dma) {
+    if (best == 0) return launch_f32_dma<128, 128>(g, transA, transB, st, best_splits);
+    if (best == 1) return launch_f32_dma<128, 64>(g, transA, transB, st, best_splits);
+    return launch_f32_dma<64, 64>(g, transA, transB, st, best_splits);
   }
   if (half) {
     if (best == 0) return launch_f32<128, 128, true>(g, transA, transB, vec, st, best_splits);

@@ -26,6 +26,13 @@ CASES = [  # M, N, K, tA, tB, acc, [(tile, splits)...]   tile 0=128x128 1=128x64
 ]
 
 
+if os.environ.get("CGRNA_VARIANT_CASES"):      # "M,N,K,ta,tb,acc:tile.splits+tile.splits;..."
+    CASES = []
+    for item in os.environ["CGRNA_VARIANT_CASES"].split(";"):
+        dims, _, forced = item.partition(":")
+        CASES.append((*[int(v) for v in dims.split(",")], [tuple(int(x) for x in f.split(".")) for f in forced.split("+")]))
+
+
 def build(specs):
     os.makedirs(VAR, exist_ok=True)
     objs = [os.path.join(PKG, "lib", f) for f in os.listdir(os.path.join(PKG, "lib")) if f.endswith(".o") and f != "gemm.o"]
@@ -55,7 +62,7 @@ def child(dtype):
         C = torch.zeros(M, N, device="cuda")
         out = []
         for t, sp in forced:
-            os.environ["CGRNA_GEMM_FORCE"] = f"{t},{sp}"
+            os.environ["CGRNA_GEMM_TUNING"] = "1"; os.environ["CGRNA_GEMM_FORCE"] = f"{t},{sp}"
             for _ in range(3):
                 ops.gemm(C, A, B, bool(ta), bool(tb), accumulate=bool(acc))
             torch.cuda.synchronize()

@@ -1,5 +1,6 @@
 """Sweep tile/split-K choices of cg_gemm (CGRNA_GEMM_FORCE) on the step's large shapes against the cost model's pick."""
-import os, sys
+import os
+os.environ.setdefault("CGRNA_GEMM_TUNING", "1")   # cg_gemm looks at its tuning hooks only when this is set at its first call, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from cycle_gan_rna_amd.ops import HipOps

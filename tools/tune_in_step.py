@@ -8,6 +8,7 @@ candidate is forced through CGRNA_GEMM_OVERRIDE and timed where it is used.  Pri
     python tools/tune_in_step.py [bf16] [--thresh=0.97] [--genes=5000] [--batch=512] > gpurun_out/in_step_f32.csv
 """
 import os
+os.environ.setdefault("CGRNA_GEMM_TUNING", "1")   # cg_gemm looks at its tuning hooks only when this is set at its first call
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
