@@ -246,6 +246,61 @@ struct StagerH {
   }
 };
 
+// The same LDS images for an operand that is ALREADY bf16 in memory (a shadow copy kept by its producer: the Adam
+// update writes one of every weight): 16-byte loads of eight elements go to LDS as they are - half the bytes, no
+// conversion.  Loads need 8-byte alignment only (base address a multiple of 8 bytes, leading dimension a multiple of
+// 4 elements, so that the row of a column slice of a 16-byte aligned matrix qualifies) and the contiguous extent must
+// be even: what a load picks up past the end of a row is cleared in pairs.
+template <int ROWS, bool MMAJ, int NT>
+struct StagerB16 {
+  static constexpr int NV = ROWS * BKH / 8 / NT;   // 16-byte loads per thread
+  static_assert(NV >= 1 && NV * NT * 8 == ROWS * BKH, "tile does not divide over the workgroup");
+  u32x4 v[NV];
+  int k0s;
+
+  __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rs, int ld, int row0, int nrows, int k0, int K) {
+    const int t = threadIdx.x;
+    k0s = k0;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int idx = t + NT * j;
+      if (!MMAJ) {
+        const int r = idx / (BKH / 8), kq = idx % (BKH / 8);
+        const int row = row0 + r, k = k0 + 8 * kq;
+        v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (row < nrows && k < K) ? ((unsigned)row * ld + k) * 2u : OOB_OFF, 0, 0);
+      } else {
+        const int k = idx / (ROWS / 8), rq = idx % (ROWS / 8);
+        const int kk = k0 + k, row = row0 + 8 * rq;
+        v[j] = __builtin_amdgcn_raw_buffer_load_b128(rs, (kk < K && row < nrows) ? ((unsigned)kk * ld + row) * 2u : OOB_OFF, 0, 0);
+      }
+    }
+  }
+  __device__ __forceinline__ static u32x4 clip8(u32x4 w, int c0, int climit) {
+#pragma unroll
+    for (int e = 1; e < 4; ++e) w[e] = c0 + 2 * e < climit ? w[e] : 0u;
+    return w;
+  }
+  __device__ __forceinline__ void store(u16* s, int row0, int nrows, int K) const {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int idx = t + NT * j;
+      if (!MMAJ) {
+        const int r = idx / (BKH / 8), kq = idx % (BKH / 8);
+        *reinterpret_cast<u32x4*>(s + r * LDH + 8 * kq) = clip8(v[j], k0s + 8 * kq, K);
+      } else {
+        const int k = idx / (ROWS / 8), rq = idx % (ROWS / 8);
+        *reinterpret_cast<u32x4*>(s + k * mmaj_stride<ROWS>() + 8 * rq) = clip8(v[j], row0 + 8 * rq, nrows);
+      }
+    }
+  }
+};
+
+template <int ROWS, bool MMAJ, bool VEC, int NT, bool SRC16>
+struct StagerSel { typedef StagerH<ROWS, MMAJ, VEC, NT> type; };
+template <int ROWS, bool MMAJ, bool VEC, int NT>
+struct StagerSel<ROWS, MMAJ, VEC, NT, true> { typedef StagerB16<ROWS, MMAJ, NT> type; };
+
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
 // The bf16x8 MFMA fragment of lane (lr = lane & 15, lg = lane >> 4): row `row0 + lr`, k = kbase + 8*lg + 0..7.
@@ -263,7 +318,8 @@ __device__ __forceinline__ bf16x8 fragment(const u16* s, int row0, int kbase, in
   return u.f;
 }
 
-template <int BM, int BN, bool TA, bool TB, bool VEC, int KW>
+// AH / BH: the operand is stored as bf16 (see StagerB16), otherwise as float32 and rounded while staged.
+template <int BM, int BN, bool TA, bool TB, bool VEC, int KW, bool AH, bool BH>
 __global__ void __launch_bounds__(256 * KW) gemm_bf16_kernel(GemmArgs g) {
   constexpr int NT = 256 * KW;                       // KW wave groups, each taking 1/KW of every slab (see gemm_f32_kernel)
   constexpr int TM = BM / 32, TN = BN / 32;          // 16x16 MFMA tiles per wave in each direction
@@ -290,8 +346,8 @@ __global__ void __launch_bounds__(256 * KW) gemm_bf16_kernel(GemmArgs g) {
 
   const __amdgpu_buffer_rsrc_t rsA = make_rsrc(g.A, g.a_bytes), rsB = make_rsrc(g.B, g.b_bytes);
   constexpr int D = prefetch_depth_bf16(BM, BN);   // register stages of global loads in flight (see gemm_f32_kernel)
-  StagerH<BM, A_MMAJ, VEC, NT> sa[D];
-  StagerH<BN, B_MMAJ, VEC, NT> sb[D];
+  typename StagerSel<BM, A_MMAJ, VEC, NT, AH>::type sa[D];
+  typename StagerSel<BN, B_MMAJ, VEC, NT, BH>::type sb[D];
   const int nk_all = (g.K + BKH - 1) / BKH;
   const int kt0 = blockIdx.y * g.kt_per_split;
   const int nk = min(nk_all, kt0 + g.kt_per_split);
@@ -893,7 +949,7 @@ void launch_splitk_reduce(const GemmArgs& g, int splits, hipStream_t st) {
   else hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(blocks), dim3(256), 0, st, g, splits);
 }
 
-template <int BM, int BN, bool HALF = false>
+template <int BM, int BN, bool HALF = false, bool AH = false, bool BH = false>
 int launch_f32(const GemmArgs& g, int transA, int transB, bool vec, hipStream_t st, int splits = 1) {
   GemmArgs a = g;
   const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
@@ -907,8 +963,8 @@ int launch_f32(const GemmArgs& g, int transA, int transB, bool vec, hipStream_t 
 #define CG_LAUNCH(TA, TB)                                                                    \
   do {                                                                                       \
     if (HALF) {                                                                              \
-      if (vec) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, TA, TB, true, KW>), grid, block, 0, st, a);   \
-      else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, TA, TB, false, KW>), grid, block, 0, st, a);      \
+      if (vec || AH || BH) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, TA, TB, true, KW, AH, BH>), grid, block, 0, st, a);   \
+      else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, TA, TB, false, KW, false, false>), grid, block, 0, st, a);            \
     } else {                                                                                 \
       if (vec) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, true, KW>), grid, block, 0, st, a);    \
       else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, false, KW>), grid, block, 0, st, a);       \
@@ -980,16 +1036,22 @@ extern "C" int cg_gemm(float* C, int ldc, const void* A, int lda, const void* B,
   if (lda < a_cols || ldb < b_cols || ldc < N) return CG_ERR_BAD_ARG;
   if (E && lde < N) return CG_ERR_BAD_ARG;
   if (aux && ldaux < N) return CG_ERR_BAD_ARG;
-  if (dtype != CG_F32 && dtype != CG_BF16) return CG_ERR_UNSUPPORTED;
-  const bool half = dtype == CG_BF16;
+  if (dtype < 0 || dtype > (CG_BF16 | CG_A_IS_BF16 | CG_B_IS_BF16)) return CG_ERR_UNSUPPORTED;
+  const bool half = (dtype & CG_BF16) != 0, ah = (dtype & CG_A_IS_BF16) != 0, bh = (dtype & CG_B_IS_BF16) != 0;
+  if ((ah || bh) && !half) return CG_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  const size_t a_bytes = ((size_t)(a_rows - 1) * lda + a_cols) * sizeof(float);
-  const size_t b_bytes = ((size_t)(b_rows - 1) * ldb + b_cols) * sizeof(float);
+  const size_t a_bytes = ((size_t)(a_rows - 1) * lda + a_cols) * (ah ? 2 : sizeof(float));
+  const size_t b_bytes = ((size_t)(b_rows - 1) * ldb + b_cols) * (bh ? 2 : sizeof(float));
+  // a bf16 operand: 8-byte aligned rows, even contiguous extent (see StagerB16)
+  if (ah && (((uintptr_t)A % 8) || lda % 4 || a_cols % 2)) return CG_ERR_UNSUPPORTED;
+  if (bh && (((uintptr_t)B % 8) || ldb % 4 || b_cols % 2)) return CG_ERR_UNSUPPORTED;
   if (a_bytes >= OOB_OFF || b_bytes >= OOB_OFF) return CG_ERR_UNSUPPORTED;   // 32-bit buffer offsets
   GemmArgs g{(const float*)A, (const float*)B, C, bias, E, aux, M, N, K, lda, ldb, ldc, lde, ldaux,
              epi, accumulate, slope, 0, 1 << 30, (float*)workspace, (unsigned)a_bytes, (unsigned)b_bytes};
+  if ((K <= 16 || N <= 2) && (ah || bh)) return CG_ERR_UNSUPPORTED;      // the plain-FMA kernels read float32
   if ((K <= 16 || N <= 2) && launch_small(g, transA, transB, st)) return cg_launch_status();
-  const bool vec = (((uintptr_t)A | (uintptr_t)B) % 16 == 0) && (lda % 4 == 0) && (ldb % 4 == 0);
+  // 16-byte loads of the float32 operands (a bf16 operand has its own conditions, checked above)
+  const bool vec = (ah || ((uintptr_t)A % 16 == 0 && lda % 4 == 0)) && (bh || ((uintptr_t)B % 16 == 0 && ldb % 4 == 0));
   // Tile and split-K choice by a cost model fitted to a sweep of the step's shapes on MI355X (microseconds).
   // A workgroup alone on a CU needs L per K slab (latency-bound); n workgroups sharing a CU overlap and finish a
   // slab every S (throughput-bound), so the busiest CU takes slabs * max(L, n*S).  Small tiles have the worse S but
@@ -1061,9 +1123,18 @@ extern "C" int cg_gemm(float* C, int ldc, const void* A, int lda, const void* B,
     return launch_f32_dma<64, 64>(g, transA, transB, st, best_splits);
   }
   if (half) {
-    if (best == 0) return launch_f32<128, 128, true>(g, transA, transB, vec, st, best_splits);
-    if (best == 1) return launch_f32<128, 64, true>(g, transA, transB, vec, st, best_splits);
-    return launch_f32<64, 64, true>(g, transA, transB, vec, st, best_splits);
+#define CG_HALF_TILES(AH, BH)                                                                            \
+  do {                                                                                                   \
+    if (best == 0) return launch_f32<128, 128, true, AH, BH>(g, transA, transB, vec, st, best_splits);   \
+    if (best == 1) return launch_f32<128, 64, true, AH, BH>(g, transA, transB, vec, st, best_splits);    \
+    return launch_f32<64, 64, true, AH, BH>(g, transA, transB, vec, st, best_splits);                    \
+  } while (0)
+    if ((ah || bh) && !vec) return CG_ERR_UNSUPPORTED;     // the float32 partner of a bf16 operand must allow 16-byte loads
+    if (ah && bh) CG_HALF_TILES(true, true);
+    if (ah) CG_HALF_TILES(true, false);
+    if (bh) CG_HALF_TILES(false, true);
+    CG_HALF_TILES(false, false);
+#undef CG_HALF_TILES
   }
   if (best == 0) return launch_f32<128, 128>(g, transA, transB, vec, st, best_splits);
   if (best == 1) return launch_f32<128, 64>(g, transA, transB, vec, st, best_splits);

@@ -275,7 +275,9 @@ class CwganEngine(EngineBase):
         assert not self.sync.enabled, "the cWGAN engine is single-rank"
 
     def _adam(self, arena):
-        self.ops.adam(arena.p, arena.g, arena.m, arena.v, arena.vmax, arena.lr_step, self.betas[0], self.betas[1], self.eps)
+        kw = {} if arena.p16 is None else dict(p16=arena.p16)
+        self.ops.adam(arena.p, arena.g, arena.m, arena.v, arena.vmax, arena.lr_step, self.betas[0], self.betas[1], self.eps,
+                      **kw)
 
     def _set_scales(self, b):
         if self._scales_b != b:

@@ -25,6 +25,7 @@ from __future__ import annotations
 
 import gc
 import math
+import weakref
 from collections import OrderedDict
 from typing import Dict, Optional
 
@@ -71,10 +72,20 @@ class Arena:
         self.vmax = ops.zeros(off)
         self.lr_step = ops.zeros(2, dtype=torch.float64)
         self.step = 0
+        # bf16 mode: a bf16 image of the parameters, rewritten by every Adam step, that the bf16 products read the
+        # weights from (call sync_shadow() after writing parameters any other way)
+        self.p16 = None
+        if getattr(ops, "precision", "fp32") == "bf16" and hasattr(ops, "register_shadow"):
+            self.p16 = ops.zeros(off, dtype=torch.bfloat16)
+            weakref.finalize(self, ops.unregister_shadow, ops.register_shadow(self.p, self.p16))
         self.net_range = {}
         for (net, _), (o, n, _) in self.offsets.items():
             lo, hi = self.net_range.get(net, (o, o))
             self.net_range[net] = (min(lo, o), max(hi, o + _pad4(n)))
+
+    def sync_shadow(self):
+        if self.p16 is not None:
+            self.ops.refresh_shadow(self.p, self.p16)
 
     def net_grad(self, net):
         lo, hi = self.net_range[net]
@@ -173,6 +184,7 @@ class Net:
                 self.B[k].copy_(v)
             elif k in self.nbt:
                 self.nbt[k] = int(v)
+        self.arena.sync_shadow()
 
 
 # --------------------------------------------------------------------------- #
@@ -850,8 +862,9 @@ class EngineBase:
 
     def _adam(self, arena):
         b1, b2 = self.adam_betas
+        kw = {} if arena.p16 is None else dict(p16=arena.p16)
         self.ops.adam(arena.p, arena.g, arena.m, arena.v, arena.vmax if self.adam_amsgrad else None, arena.lr_step,
-                      float(b1), float(b2), 1e-8)
+                      float(b1), float(b2), 1e-8, **kw)
 
     # ---- HIP graphs ------------------------------------------------------------------
     def enable_graphs(self):
@@ -935,6 +948,8 @@ class StepEngine(EngineBase):
             for k in order[n]:
                 net.P[k].copy_(ops.to_device(split[n][0][k].detach().float()))
             self.nets[n] = net
+        self.arena_g.sync_shadow()
+        self.arena_d.sync_shadow()
         # opt-in departures from GAN_functions.py for the curriculum training of GAN_optimize_optuna.ipynb cell-1
         # (absent keys = the reference's step): plain Adam with the config's betas, one lr for all three
         # optimizers, Poisson cycle loss, loss weights handed in per epoch

@@ -65,6 +65,8 @@ class HipOps:
         # one stream run in order, so one buffer per use serves every call
         # (one pair per stream, because two streams may run kernels at the same time)
         self._scratch = {}
+        # float32 arenas that have a bf16 shadow: (first byte, one past the last byte, shadow tensor)
+        self._shadows = []
 
     def _ws(self):
         key = torch.cuda.current_stream(self.device).cuda_stream
@@ -112,6 +114,35 @@ class HipOps:
     def to_device(self, t):
         return t.to(self.device)
 
+    # -- bf16 shadows -----------------------------------------------------------
+    def register_shadow(self, f32_flat, bf16_flat):
+        """`bf16_flat` holds (and its owner keeps up to date) the bf16 image of the contiguous float32 tensor
+        `f32_flat`: products of the bf16 mode read an operand that is a view into `f32_flat` from the shadow instead
+        (half the bytes, no conversion while staging).  The shadow is filled here."""
+        assert f32_flat.is_contiguous() and bf16_flat.is_contiguous() and f32_flat.numel() == bf16_flat.numel()
+        assert bf16_flat.dtype == torch.bfloat16 and bf16_flat.data_ptr() % 16 == 0 and f32_flat.data_ptr() % 16 == 0
+        self._shadows.append((f32_flat.data_ptr(), f32_flat.data_ptr() + 4 * f32_flat.numel(), bf16_flat))
+        self.refresh_shadow(f32_flat, bf16_flat)
+        return f32_flat.data_ptr()
+
+    def unregister_shadow(self, key):
+        """Forget the shadow registered for the arena at address `key` (its owner is gone; the address range may be
+        handed to another tensor)."""
+        self._shadows = [e for e in self._shadows if e[0] != key]
+
+    def refresh_shadow(self, f32_flat, bf16_flat):
+        n = f32_flat.numel()
+        st = self.lib.cg_to_bf16(_ptr(bf16_flat), n, _ptr(f32_flat), n, 1, n, self._stream())
+        _lib.check(st, "cg_to_bf16")
+
+    def _shadow_ptr(self, t):
+        """Device address of the bf16 image of the float32 view `t` (same leading dimension, in elements), or None."""
+        p = t.data_ptr()
+        for lo, hi, sh in self._shadows:
+            if lo <= p < hi:
+                return sh.data_ptr() + (p - lo) // 2
+        return None
+
     # -- GEMM -----------------------------------------------------------------
     def gemm(self, Cm, A, B, transA=False, transB=False, bias=None, epi=EPI_NONE, E=None, aux=None, slope=0.0,
              accumulate=False, dtype=None):
@@ -129,16 +160,28 @@ class HipOps:
             assert tuple(aux.shape) == (M, N)
         if dtype is None:
             dtype = 1 if (self.precision == "bf16" and M >= 128 and N >= 128 and K >= 256) else 0
+        pA, pB = _ptr(A), _ptr(B)
+        if dtype == 1 and self._shadows:
+            # an operand that lives in an arena with a bf16 shadow (the weights) is read from the shadow; the library's
+            # conditions: 8-byte aligned rows, even contiguous extent
+            sa, sb = self._shadow_ptr(A), self._shadow_ptr(B)
+            if sb is not None and sb % 8 == 0 and _ld(B) % 4 == 0 and B.shape[1] % 2 == 0 and \
+                    (A.data_ptr() % 16 == 0 and _ld(A) % 4 == 0):
+                pB, dtype = C.c_void_p(sb), dtype | 2
+            if sa is not None and sa % 8 == 0 and _ld(A) % 4 == 0 and A.shape[1] % 2 == 0 and \
+                    (dtype & 2 or (B.data_ptr() % 16 == 0 and _ld(B) % 4 == 0)):
+                pA, dtype = C.c_void_p(sa), dtype | 4
         if self._gemm_events is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(self.device))
-        st = self.lib.cg_gemm(_ptr(Cm), _ld(Cm), _ptr(A), _ld(A), _ptr(B), _ld(B), M, N, K, int(transA), int(transB),
+        st = self.lib.cg_gemm(_ptr(Cm), _ld(Cm), pA, _ld(A), pB, _ld(B), M, N, K, int(transA), int(transB),
                               dtype, _ptr(bias), epi, _ptr(E), _ld(E), _ptr(aux), _ld(aux), float(slope),
                               int(accumulate), _ptr(self._ws()[0]), self._ws()[0].numel() * 4, self._stream())
         if self._gemm_events is not None:
             e1.record(torch.cuda.current_stream(self.device))
+            elem = lambda flag: 2.0 if dtype & flag else 4.0  # noqa: E731
             self._gemm_events.append((e0, e1, 2.0 * M * N * K,
-                                      4.0 * (M * K + K * N + M * N * (2 if accumulate else 1)),
+                                      elem(4) * M * K + elem(2) * K * N + 4.0 * M * N * (2 if accumulate else 1),
                                       (M, N, K, int(transA), int(transB), int(accumulate), dtype)))
         _lib.check(st, "cg_gemm")
 
@@ -394,13 +437,14 @@ class HipOps:
         _lib.check(st, "cg_sum_parts")
 
     # -- optimizer ------------------------------------------------------------------
-    def adam(self, p, g, m, v, vmax, lr_step, beta1, beta2, eps):
-        """vmax None: plain Adam (no running maximum of v)."""
+    def adam(self, p, g, m, v, vmax, lr_step, beta1, beta2, eps, p16=None):
+        """vmax None: plain Adam (no running maximum of v).  p16: bf16 shadow of p, rewritten with the new values."""
         assert lr_step.dtype == torch.float64 and lr_step.numel() == 2
         n = p.numel()
         assert g.numel() == n and m.numel() == n and v.numel() == n and (vmax is None or vmax.numel() == n)
+        assert p16 is None or (p16.dtype == torch.bfloat16 and p16.numel() == n and p16.is_contiguous())
         st = self.lib.cg_adam_amsgrad(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(vmax), n, _ptr(lr_step), beta1, beta2,
-                                      eps, None, self._stream())
+                                      eps, _ptr(p16), self._stream())
         _lib.check(st, "cg_adam_amsgrad")
 
     # -- latent ResidualBlock on tokens (fused) ------------------------------------------

@@ -38,9 +38,11 @@ extern "C" {
                         /* C = h * pm; AUX = pm (if AUX != NULL)                      */
 #define CG_EPI_MUL 2    /* C = (acc + bias) * E                                       */
 
-/* A/B element types of cg_gemm */
+/* cg_gemm `dtype`: the arithmetic, and (flags, with CG_BF16 only) how the operands are stored */
 #define CG_F32 0
 #define CG_BF16 1
+#define CG_B_IS_BF16 2   /* B is stored as bf16 (ldb in bf16 elements) */
+#define CG_A_IS_BF16 4   /* A is stored as bf16 (lda in bf16 elements) */
 
 int cg_version(void);
 
@@ -52,8 +54,12 @@ int cg_version(void);
  *   transA = 0: A is stored [M][K];  1: A is stored [K][M]
  *   transB = 0: B is stored [K][N];  1: B is stored [N][K]
  *   dtype  = CG_F32 (v_mfma_f32_32x32x2_f32, exact float32 products) or
- *            CG_BF16 (A and B are still float32 in memory; they are rounded to bf16 while being
- *            staged into LDS and multiplied with v_mfma_f32_16x16x32_bf16, float32 accumulate)
+ *            CG_BF16 (operands rounded to bf16, multiplied with v_mfma_f32_16x16x32_bf16, float32
+ *            accumulate).  With CG_BF16 alone A and B are float32 in memory and are rounded while
+ *            being staged into LDS; CG_BF16 | CG_B_IS_BF16 / CG_A_IS_BF16: that operand is already
+ *            stored as bf16 (a shadow copy such as the one cg_adam_amsgrad writes of the weights;
+ *            half the bytes, no conversion) - its address must be a multiple of 8 bytes, its leading
+ *            dimension a multiple of 4 and its contiguous extent even, else CG_ERR_UNSUPPORTED
  * Replaces nn.Linear forward (GAN_functions.py:59,62,89,92,97-98,117,120,124,
  * 165,169,172,174; transA=0, transB=1), its input gradient (0,0), its weight
  * gradient (1,0), and the second-order products of the gradient penalty

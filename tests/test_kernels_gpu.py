@@ -80,6 +80,47 @@ def test_gemm_bf16(ops, M, N, K, ta, tb):
     close(got, exact, 2e-2, "gemm bf16 vs float64")
 
 
+@pytest.mark.parametrize("M,N,K,ta,tb,lda_pad,ldb_pad,flags", [
+    (512, 1024, 5012, 0, 1, 0, 0, 2),      # weights [N][K] stored bf16, rows 8-byte aligned only (5012 * 2 bytes)
+    (512, 1024, 5000, 0, 1, 0, 12, 2),     # a column slice of a wider bf16 matrix
+    (512, 5000, 1024, 0, 0, 0, 12, 2),     # input gradient: weights [K][N] read along the rows, N not a multiple of 8
+    (130, 268, 512, 0, 0, 0, 0, 2), (96, 160, 200, 1, 0, 0, 0, 2),
+    (512, 2048, 5000, 0, 1, 0, 0, 6),      # both operands stored bf16
+    (512, 1024, 300, 1, 0, 4, 0, 4),       # A stored bf16 and read along its rows
+    (200, 136, 1030, 0, 1, 2, 6, 6)])
+def test_gemm_bf16_operands_stored_as_bf16(ops, M, N, K, ta, tb, lda_pad, ldb_pad, flags):
+    """CG_BF16 | CG_B_IS_BF16 / CG_A_IS_BF16 through the C ABI: an operand that is already bf16 in memory gives the
+    same result, bit for bit, as the float32 copy of the same (bf16-representable) values rounded while staged."""
+    import ctypes as C
+    from cycle_gan_rna_amd import _lib
+    lib = _lib.load()
+    ar, ac = (K, M) if ta else (M, K)
+    br, bc = (N, K) if tb else (K, N)
+    A = rnd(ar, ac + lda_pad, seed=1).bfloat16().float()
+    B = rnd(br, bc + ldb_pad, seed=2).bfloat16().float()
+    Ad, Bd = dev(A), dev(B)
+    A16, B16 = Ad.bfloat16(), Bd.bfloat16()
+    ref = torch.full((M, N), float("nan")).cuda()
+    ops.gemm(ref, Ad[:, :ac], Bd[:, :bc], bool(ta), bool(tb), dtype=1)
+    got = torch.full((M, N), float("nan")).cuda()
+    ws = torch.empty(8 << 20, device="cuda")
+    pa = (A16 if flags & 4 else Ad).data_ptr()
+    pb = (B16 if flags & 2 else Bd).data_ptr()
+    st = lib.cg_gemm(C.c_void_p(got.data_ptr()), N, C.c_void_p(pa), ac + lda_pad, C.c_void_p(pb), bc + ldb_pad, M, N, K,
+                     ta, tb, 1 | flags, None, 0, None, 0, None, 0, 0.0, 0, C.c_void_p(ws.data_ptr()), ws.numel() * 4,
+                     C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert st == 0, st
+    torch.cuda.synchronize()
+    exp = torch.empty(M, N, dtype=torch.float64)
+    cpu.gemm(exp, A[:, :ac].double(), B[:, :bc].double(), bool(ta), bool(tb))
+    close(got, exp, 2e-5, "gemm with bf16-stored operands")
+    assert torch.equal(got, ref)
+    # an odd contiguous extent or a misaligned row start is refused, not mis-read
+    st = lib.cg_gemm(C.c_void_p(got.data_ptr()), N, C.c_void_p(pa), ac + lda_pad, C.c_void_p(pb + 2), bc + ldb_pad, M, N, K,
+                     ta, tb, 3, None, 0, None, 0, None, 0, 0.0, 0, None, 0, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert st == -2
+
+
 def test_gemm_bf16_exact_on_small_integers(ops):
     M, N, K = 96, 160, 200
     A = torch.randint(-3, 4, (K, M), generator=torch.Generator().manual_seed(0)).float()
