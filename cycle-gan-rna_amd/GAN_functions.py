@@ -627,12 +627,15 @@ def train_enhanced_cycle_gan(g_m2h, g_h2m, d_m, d_h, mouse_adata, human_adata,
                     hd, hc = next(human_iter)
                 n = min(md.size(0), hd.size(0))                                                # :315-319
                 yield i, (md[:n], hd[:n], mc[:n], hc[:n])
-        # one batch is drawn ahead of the iteration that uses it (within the epoch only), so that the engine can
-        # be told the next batch; the draws of the shuffling keep their order
+        # With lookahead one batch is drawn ahead of the iteration that uses it (within the epoch only), so that the
+        # engine can be told the next batch; the draws of the shuffling keep their order among themselves.  Without
+        # it every batch is drawn when its iteration starts, as in the reference: a loader that restarts in the
+        # middle of an epoch draws its new permutation from the global generator between the noise draws of two
+        # iterations, and replayed host noise ('noise': 'host_replay') must see exactly that order.
         batches = epoch_batches()
         cur = next(batches, None)
         while cur is not None:
-            nxt = next(batches, None)
+            nxt = next(batches, None) if eng.lookahead else None
             i, batch = cur
             if hasattr(noise, "begin_step"):
                 noise.begin_step()
@@ -641,7 +644,7 @@ def train_enhanced_cycle_gan(g_m2h, g_h2m, d_m, d_h, mouse_adata, human_adata,
                 last = out
                 for k, src in key_map:
                     acc[k].append(out[src])
-            cur = nxt
+            cur = nxt if eng.lookahead else next(batches, None)
         if config['use_lr_decay']:                                                             # :421
             current_lr, new_lr = _lr_decay_step(config, epoch)
             if new_lr is not None:

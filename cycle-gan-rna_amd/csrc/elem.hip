@@ -152,6 +152,27 @@ __global__ void gp_interp_kernel(float* out, int ldo, const float* real, int ldr
   }
 }
 
+// The critic step's three input batches in one pass: rows [0, M) of `out` <- real, [M, 2M) <- fake, [2M, 3M) <- the
+// interpolates; and their labels (n_cov int64 per row): real's, fake's, fake's.
+__global__ void critic_inputs_kernel(float* out, int ldo, const float* real, int ldr, const float* fake, int ldf,
+                                     const float* alpha, int M, int G, int64_t* lab_out, const int64_t* real_lab,
+                                     const int64_t* fake_lab, int n_cov) {
+  CG_2D_LOOP(M, G) {
+    const float a = alpha[m], r = real[(size_t)m * ldr + col], f = fake[(size_t)m * ldf + col];
+    out[(size_t)m * ldo + col] = r;
+    out[(size_t)(M + m) * ldo + col] = f;
+    out[(size_t)(2 * M + m) * ldo + col] = a * r + (1.f - a) * f;
+  }
+  if (lab_out && blockIdx.x == 0 && blockIdx.y == 0) {
+    const int t = threadIdx.y * blockDim.x + threadIdx.x, nt = blockDim.x * blockDim.y;
+    for (int i = t; i < M * n_cov; i += nt) {
+      lab_out[i] = real_lab[i];
+      lab_out[M * n_cov + i] = fake_lab[i];
+      lab_out[2 * M * n_cov + i] = fake_lab[i];
+    }
+  }
+}
+
 __global__ void __launch_bounds__(256) gp_penalty_kernel(float* V, int ldv, float* rowpen, const float* UX, int ldu,
                                                          float lam2_over_m, int G) {
   __shared__ float lds[17];
@@ -499,6 +520,17 @@ extern "C" int cg_gp_interp(float* out, int ldo, const float* real, int ldr, con
   if (!out || !real || !fake || !alpha || M <= 0 || G <= 0 || ldo < G || ldr < G || ldf < G) return CG_ERR_BAD_ARG;
   Grid2 g = grid2(M, G);
   hipLaunchKernelGGL(gp_interp_kernel, g.grid, g.block, 0, ST, out, ldo, real, ldr, fake, ldf, alpha, M, G);
+  return cg_launch_status();
+}
+
+extern "C" int cg_critic_inputs(float* out, int ldo, const float* real, int ldr, const float* fake, int ldf,
+                                const float* alpha, int M, int G, int64_t* lab_out, const int64_t* real_lab,
+                                const int64_t* fake_lab, int n_cov, void* stream) {
+  if (!out || !real || !fake || !alpha || M <= 0 || G <= 0 || ldo < G || ldr < G || ldf < G) return CG_ERR_BAD_ARG;
+  if (lab_out && (!real_lab || !fake_lab || n_cov <= 0)) return CG_ERR_BAD_ARG;
+  Grid2 g = grid2(M, G);
+  hipLaunchKernelGGL(critic_inputs_kernel, g.grid, g.block, 0, ST, out, ldo, real, ldr, fake, ldf, alpha, M, G, lab_out,
+                     real_lab, fake_lab, n_cov);
   return cg_launch_status();
 }
 

@@ -921,6 +921,29 @@ __global__ void __launch_bounds__(256) gemm_small_n_kernel(GemmArgs g, Strides s
   }
 }
 
+// M <= 2 with A stored [K][M] and B stored [K][N] (a weight gradient of the critic's one-column head: dval^T a3): a
+// workgroup owns 32 columns, its 32 row lanes stride over k, partial sums are added in lane order.
+__global__ void __launch_bounds__(1024) gemm_small_m_kernel(GemmArgs g) {
+  __shared__ float lds[2][32][33];
+  const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5, col = blockIdx.x * 32 + c;
+  float acc[2] = {0.f, 0.f};
+  if (col < g.N)
+    for (int k = r0; k < g.K; k += 32) {
+      const float b = g.B[(size_t)k * g.ldb + col];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+        if (m < g.M) acc[m] += g.A[(size_t)k * g.lda + m] * b;
+    }
+  lds[0][r0][c] = acc[0];
+  lds[1][r0][c] = acc[1];
+  __syncthreads();
+  if (r0 < g.M && col < g.N) {
+    float h = g.bias ? g.bias[col] : 0.f;
+    for (int r = 0; r < 32; ++r) h += lds[r0][r][c];
+    epilogue_store(g, r0, col, h);
+  }
+}
+
 // Returns true when one of the kernels above took the product.
 bool launch_small(const GemmArgs& g, int transA, int transB, hipStream_t st) {
   const Strides s{transA ? 1 : g.lda, transA ? g.lda : 1, transB ? 1 : g.ldb, transB ? g.ldb : 1};
@@ -928,6 +951,10 @@ bool launch_small(const GemmArgs& g, int transA, int transB, hipStream_t st) {
     size_t blocks = ((size_t)g.M * g.N + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(gemm_small_k_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g, s);
+    return true;
+  }
+  if (g.M <= 2 && transA && !transB) {
+    hipLaunchKernelGGL(gemm_small_m_kernel, dim3((g.N + 31) / 32), dim3(1024), 0, st, g);
     return true;
   }
   // a few columns: every wave reads B once per row it owns, which stays cheap while B is a few vectors (measured:
@@ -1048,8 +1075,9 @@ extern "C" int cg_gemm(float* C, int ldc, const void* A, int lda, const void* B,
   if (a_bytes >= OOB_OFF || b_bytes >= OOB_OFF) return CG_ERR_UNSUPPORTED;   // 32-bit buffer offsets
   GemmArgs g{(const float*)A, (const float*)B, C, bias, E, aux, M, N, K, lda, ldb, ldc, lde, ldaux,
              epi, accumulate, slope, 0, 1 << 30, (float*)workspace, (unsigned)a_bytes, (unsigned)b_bytes};
-  if ((K <= 16 || N <= 2) && (ah || bh)) return CG_ERR_UNSUPPORTED;      // the plain-FMA kernels read float32
-  if ((K <= 16 || N <= 2) && launch_small(g, transA, transB, st)) return cg_launch_status();
+  const bool tiny = K <= 16 || N <= 2 || (M <= 2 && transA && !transB);
+  if (tiny && (ah || bh)) return CG_ERR_UNSUPPORTED;      // the plain-FMA kernels read float32
+  if (tiny && launch_small(g, transA, transB, st)) return cg_launch_status();
   // 16-byte loads of the float32 operands (a bf16 operand has its own conditions, checked above)
   const bool vec = (ah || ((uintptr_t)A % 16 == 0 && lda % 4 == 0)) && (bh || ((uintptr_t)B % 16 == 0 && ldb % 4 == 0));
   // Tile and split-K choice by a cost model fitted to a sweep of the step's shapes on MI355X (microseconds).

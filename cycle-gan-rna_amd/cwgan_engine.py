@@ -117,7 +117,6 @@ class CriticW:
         self.act = [Z(R, w) for w in D_WIDTHS]
         self.pm = [Z(R, w) for w in D_WIDTHS]
         self.val, self.dval = Z(R, 1), Z(R, 1)
-        self._dval_key = None
         self.g = [Z(R, w) for w in D_WIDTHS]          # first-order chains (both branches use disjoint row ranges)
         self.h = [Z(max_b, w) for w in D_WIDTHS]      # second-order chain of the penalty
         self.demb = Z(R, max(self.E, 1))
@@ -192,18 +191,14 @@ class CriticW:
         """Critic update: gradients of sum_s scales[s] * sum(validity of segment s) over the first len(scales)
         segments."""
         R = len(scales) * b
-        if self._dval_key != (b, tuple(scales)):
-            self.dval[:R].copy_(self.ops.to_device(torch.tensor(scales, dtype=torch.float32).repeat_interleave(b)[:, None]))
-            self._dval_key = (b, tuple(scales))
+        for k, sc in enumerate(scales):          # on the device at every call, so that a captured step carries the writes
+            self.dval[k * b:(k + 1) * b].fill_(sc)
         self._chain(slice(0, R), self.dval[:R], self.net.G, True, False)
 
     def backward_input(self, b, seg, scale, dx_out):
         """Generator update: dx_out = d(scale * sum(validity of segment seg))/d(input batch)."""
         rows = slice(seg * b, (seg + 1) * b)
-        key = ("in", b, seg, scale)
-        if self._dval_key != key:
-            self.dval[rows].fill_(scale)
-            self._dval_key = key
+        self.dval[rows].fill_(scale)
         self._chain(rows, self.dval[rows], None, False, True, dx_out)
 
     def gp_backward(self, b, seg, lambda_gp, red, slot):

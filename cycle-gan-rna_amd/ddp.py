@@ -27,13 +27,13 @@ class GradSync:
         self.bucket_elems = bucket_bytes // 4
         self.comm = torch.cuda.Stream(device=self.device) if (self.enabled and self.is_cuda) else None
         self.pending = []
-        # The gloo backend (CPU clusters and tests; RCCL is the production backend) stages a device tensor through
-        # the host on a stream of its own, which it makes wait for the calling stream.  On this stack that wait does
-        # not complete (or takes seconds) when the calling stream still has a kernel in flight - reproduced without
-        # this package by tools/diag_gloo_allreduce.py: all_reduce, a scaling kernel, all_reduce on one stream stalls
-        # in the second call; with the stream drained before each call it never does.  So gloo gets a drained
-        # stream before every collective.
-        self.host_sync = self.enabled and self.is_cuda and dist.get_backend() == "gloo"
+        # The gloo backend (CPU clusters and tests; RCCL is the production backend) handed a device tensor stages it
+        # through the host on a stream of its own, which it makes wait for the calling stream.  On this stack that wait
+        # stalls (seconds to forever) when work is in flight on the device - reproduced without this package by
+        # tools/diag_gloo_allreduce.py: all_reduce, a scaling kernel, all_reduce on one stream stalls in the second
+        # call - and, with two processes sharing one GPU, now and then even behind a drained stream.  So for gloo the
+        # staging is done here: device -> host copy, all_reduce of the host tensor, copy back.
+        self.host_staged = self.enabled and self.is_cuda and dist.get_backend() == "gloo"
 
     def launch(self, flat_grad, ranges=None):
         """Start averaging `flat_grad` (a contiguous 1-D tensor) over the ranks, or only its element ranges
@@ -50,15 +50,16 @@ class GradSync:
                 dist.all_reduce(chunk, op=dist.ReduceOp.SUM)
                 chunk.div_(self.world)
             return
-        if self.host_sync:
-            torch.cuda.synchronize(self.device)
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(self.device))
         self.comm.wait_event(ready)
         with torch.cuda.stream(self.comm):
             for chunk in chunks:
-                if self.host_sync:
-                    self.comm.synchronize()
+                if self.host_staged:
+                    host = chunk.to("cpu")                 # waits for the chunk's producers (the side stream is drained)
+                    dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                    chunk.copy_(host.mul_(1.0 / self.world))
+                    continue
                 # sum + scale rather than ReduceOp.AVG: identical on RCCL, and also valid on gloo, which lets
                 # the device code path be exercised by two ranks sharing one GPU
                 dist.all_reduce(chunk, op=dist.ReduceOp.SUM)
@@ -75,8 +76,12 @@ class GradSync:
 
     def sum_scalars(self, t):
         """Sum a small tensor over ranks, in place, on the current stream."""
-        if self.host_sync:
-            torch.cuda.synchronize(self.device)
-        if self.enabled:
+        if not self.enabled:
+            return t
+        if self.is_cuda and self.host_staged:
+            host = t.to("cpu")
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            t.copy_(host)
+        else:
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return t

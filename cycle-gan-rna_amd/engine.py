@@ -624,7 +624,6 @@ class CriticStack:
         self.a3, self.pm3 = Z(S * B, 256), Z(S * B, 256)
         self.val = Z(S * B, 1)
         self.dval = Z(S * B, 1)
-        self._dval_b = None
         self.ones = ops.to_device(torch.ones(B, 1))
         self.g256, self.g512, self.g1024a, self.g1024b = Z(S * B, 256), Z(S * B, 512), Z(S * B, 1024), Z(S * B, 1024)
         self.h256, self.h512, self.h1024a, self.h1024b = Z(B, 256), Z(B, 512), Z(B, 1024), Z(B, 1024)
@@ -681,9 +680,10 @@ class CriticStack:
         assert self.nx == self.S
         ns = len(scales)
         R = ns * b
-        if self._dval_b != (b, tuple(scales)):
-            self.dval[:R].copy_(ops.to_device(torch.tensor(scales, dtype=torch.float32).repeat_interleave(b)[:, None]))
-            self._dval_b = (b, tuple(scales))
+        # Written on the device at every call: a captured step must carry these writes itself (a host-side "already
+        # holds these values" test would be frozen into the graph, and a batch of another size in between rewrites them).
+        for k, sc in enumerate(scales):
+            self.dval[k * b:(k + 1) * b].fill_(sc)
         W1 = P["model.0.weight"]
         dval, dh3 = self.dval[:R], self.g256[:R]
         ops.gemm(G["model.9.weight"], dval, self.a3[:R], True, False, accumulate=True)
@@ -814,13 +814,29 @@ class EngineBase:
         used = (self.sides if self._lane_sides is None else self._lane_sides)[:len(branches) - 1]
         assert len(used) == len(branches) - 1, "this lane has too few side streams"
         for st in used:
-            st.wait_stream(main)
+            self._after(st, main)
         branches[0]()
         for st, fn in zip(used, branches[1:]):
             with torch.cuda.stream(st):
                 fn()
         for st in used:
-            main.wait_stream(st)
+            self._after(main, st)
+
+    _edge_events = None
+
+    def _after(self, waiter, other):
+        """Work queued on `waiter` from now on starts after what `other` has queued so far.  Like
+        waiter.wait_stream(other), but with one long-lived event per (other, waiter) pair instead of an event made
+        and destroyed per call while its record and its wait are still queued: a step forks and joins hundreds of
+        times, and an event is only safe to reuse, never to outlive."""
+        if self._edge_events is None:
+            self._edge_events = {}
+        key = (other.cuda_stream, waiter.cuda_stream)
+        ev = self._edge_events.get(key)
+        if ev is None:
+            ev = self._edge_events[key] = torch.cuda.Event()
+        ev.record(other)
+        waiter.wait_event(ev)
 
     def _two(self, first, second):
         self._many(first, second)
@@ -848,12 +864,12 @@ class EngineBase:
         ring["next"] = (i + 1) % PIN_SLOTS
         if ring["done"][i] is not None:
             ring["done"][i].synchronize()
+        else:
+            ring["done"][i] = torch.cuda.Event()        # one event per slot, recorded again at every use of the slot
         host = ring["buf"][i]
         host[0], host[1] = lr, float(arena.step)
         arena.lr_step.copy_(host, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.ops.device))
-        ring["done"][i] = ev
+        ring["done"][i].record(torch.cuda.current_stream(self.ops.device))
 
     # betas (0.5, 0.9) with amsgrad: GAN_functions.py:223-225.  A subclass (or its config) may ask for torch.optim.Adam's
     # defaults instead, as GAN_optimize_optuna.ipynb cell-1 (train_with_curriculum) builds its optimizers.
@@ -1113,11 +1129,12 @@ class StepEngine(EngineBase):
 
         def critic_fwd(name, real, real_lab, fake, fake_lab, s0):
             ds = self.dstack[name]
-            ds.load(0, b, real, real_lab)
-            ds.load(1, b, fake, fake_lab)
-            ds.load(2, b, None, fake_lab)
             m1, m2, alpha = drawn[name] if drawn else self._critic_noise(noise, b, 3, alpha_before=2)
-            ops.gp_interp(ds.x_seg(2, b), real, fake, alpha)
+            # real | generated | interpolated batch and their labels into the stacked input, one launch
+            ds.have_labels = real_lab is not None
+            ops.critic_inputs(ds.x[:3 * b], ds.lab[:3 * b] if ds.have_labels else None, real, fake, alpha,
+                              real_lab.contiguous() if ds.have_labels else None,
+                              fake_lab.contiguous() if ds.have_labels else None)
             val, _ = ds.forward(b, m1, m2, (0, 1, 2))
             ops.reduce_sum(self.red, s0, val[:b])
             ops.reduce_sum(self.red, s0 + 1, val[b:2 * b])
@@ -1406,6 +1423,9 @@ class StepEngine(EngineBase):
         self.gen_d = [{"g_m2h": GenPass(self, N["g_m2h"], gm, gh, B), "g_h2m": GenPass(self, N["g_h2m"], gh, gm, B)}
                       for _ in range(2)]
         self._d_states = [None, None]
+        # the last full-size state of each set: a replayed graph does not run the host code that records the state,
+        # so after a ragged batch (run eagerly, on the same set) the full-size record is put back from here
+        self._d_states_full = [None, None]
         # the batch of workspace set s has one fixed home: the set is filled either by "dgen{s}" or by
         # "pair{1-s}n", and the critics' graphs that read it later are captured once, with these addresses
         self._real = [None, None]
@@ -1439,6 +1459,8 @@ class StepEngine(EngineBase):
             body(*tensors, noise)
 
     def _real_set(self, s, like):
+        if like[0].shape[0] != self.max_b:       # a ragged batch runs eagerly, on the caller's tensors
+            return None
         if self._real[s] is None:
             self._real[s] = [torch.empty_like(t) for t in like]
         return self._real[s]
@@ -1450,8 +1472,13 @@ class StepEngine(EngineBase):
             def gen(which, x, lab):
                 out[which] = self.gen_d[s][which].forward(x, lab, noise)
             self._two(lambda: gen("g_m2h", mouse, mouse_cat), lambda: gen("g_h2m", human, human_cat))
-            self._d_states[s] = (mouse, human, mouse_cat, human_cat, noise, out["g_m2h"], out["g_h2m"])
+            self._set_d_state(s, (mouse, human, mouse_cat, human_cat, noise, out["g_m2h"], out["g_h2m"]))
         return body
+
+    def _set_d_state(self, s, state):
+        self._d_states[s] = state
+        if state[0].shape[0] == self.max_b:
+            self._d_states_full[s] = state
 
     def _d_crit_set(self, s):
         def body(noise):
@@ -1478,7 +1505,7 @@ class StepEngine(EngineBase):
             self._d_noise = self._draw_d_noise(noise, mouse.shape[0])
             lanes = (self.ahead, self.ahead_sides[0])      # one generator each, both forked from the main stream
             for st in lanes:
-                st.wait_stream(main)
+                self._after(st, main)
             passes = self.gen_a if mode == "g" else self.gen_d[1 - s]
             with self._Lane(self, noise, lanes[0]):
                 if mode == "g":
@@ -1489,10 +1516,10 @@ class StepEngine(EngineBase):
             if mode == "g":
                 self._g_state = (mouse, human, mouse_cat, human_cat, dict(fh=out_h, fm=out_m), noise)
             else:
-                self._d_states[1 - s] = (mouse, human, mouse_cat, human_cat, noise, out_h, out_m)
+                self._set_d_state(1 - s, (mouse, human, mouse_cat, human_cat, noise, out_h, out_m))
             self._d_crit_set(s)(noise)
             for st in lanes:
-                main.wait_stream(st)
+                self._after(main, st)
             if mode == "g":
                 self._g_tail(noise)
         return body
@@ -1513,6 +1540,8 @@ class StepEngine(EngineBase):
             s = self._dset = 1 - self._dset
             self._run_graph_or_eager(f"dgen{s}", self._d_gen_set(s), ins, noise, b, self._real_set(s, ins))
         self._pre = None
+        if self.use_graphs and b == self.max_b and self._d_states_full[s] is not None:
+            self._d_states[s] = self._d_states_full[s]
         self._begin_opt(self.arena_d, self.lr_d)
         if do_g:
             self._begin_opt(self.arena_g, self.lr_g)

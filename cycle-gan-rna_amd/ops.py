@@ -9,6 +9,7 @@ file, and there is no fallback when the library or the GPU is missing.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -74,6 +75,9 @@ class HipOps:
         if ws is None:
             ws = [torch.empty(32 << 20, dtype=torch.float32, device=self.device),     # 128 MiB split-K slabs
                   torch.empty(1 << 20, dtype=torch.float64, device=self.device)]      # 8 MiB BatchNorm chunk sums
+            if os.environ.get("CGRNA_POISON_SCRATCH"):      # debugging aid: a kernel that reads scratch it did not write shows as NaN
+                ws[0].fill_(float("nan"))
+                ws[1].fill_(float("nan"))
             self._scratch[key] = ws
         return ws
 
@@ -321,6 +325,20 @@ class HipOps:
         st = self.lib.cg_gp_interp(_ptr(out), _ld(out), _ptr(real), _ld(real), _ptr(fake), _ld(fake), _ptr(alpha), M,
                                    G, self._stream())
         _lib.check(st, "cg_gp_interp")
+
+    def critic_inputs(self, out, lab_out, real, fake, alpha, real_lab, fake_lab):
+        """out (3M, G) <- [real; fake; interpolates], lab_out (3M, n_cov) <- [real_lab; fake_lab; fake_lab]."""
+        M, G = real.shape
+        assert out.shape == (3 * M, G) and fake.shape == (M, G) and alpha.numel() == M
+        n_cov = 0
+        if lab_out is not None:
+            n_cov = real_lab.shape[1]
+            _chk(lab_out, torch.int64), _chk(real_lab, torch.int64), _chk(fake_lab, torch.int64)
+            assert lab_out.shape == (3 * M, n_cov) and real_lab.shape == (M, n_cov) and fake_lab.shape == (M, n_cov)
+            assert lab_out.is_contiguous() and real_lab.is_contiguous() and fake_lab.is_contiguous()
+        st = self.lib.cg_critic_inputs(_ptr(out), _ld(out), _ptr(real), _ld(real), _ptr(fake), _ld(fake), _ptr(alpha), M,
+                                       G, _ptr(lab_out), _ptr(real_lab), _ptr(fake_lab), n_cov, self._stream())
+        _lib.check(st, "cg_critic_inputs")
 
     def gp_penalty(self, V, rowpen, UX, lambda_gp):
         M, G = UX.shape

@@ -231,6 +231,14 @@ int cg_libsize_bwd(float* dX, int lddx, const float* dY, int lddy, const float* 
 int cg_gp_interp(float* out, int ldo, const float* real, int ldr, const float* fake, int ldf,
                  const float* alpha, int M, int G, void* stream);
 /*
+ * The three input batches of a critic step in one pass (:326-336): rows [0, M) of `out` <- real, [M, 2M) <- fake,
+ * [2M, 3M) <- alpha*real + (1-alpha)*fake; lab_out (3M x n_cov int64, may be NULL) <- real_lab, fake_lab, fake_lab
+ * (the critic sees the generated and the interpolated batch with the labels of the generated one, :328-329).
+ */
+int cg_critic_inputs(float* out, int ldo, const float* real, int ldr, const float* fake, int ldf,
+                     const float* alpha, int M, int G, int64_t* lab_out, const int64_t* real_lab,
+                     const int64_t* fake_lab, int n_cov, void* stream);
+/*
  * Row norms and the penalty (:203): n_m = ||UX[m,:]||_2; rowpen[m] = (n_m-1)^2
  * (their mean is the penalty); V[m,:] = (lambda*2/M)*((n_m-1)/n_m)*UX[m,:] is the
  * gradient of lambda*penalty w.r.t. UX.  V may alias UX.

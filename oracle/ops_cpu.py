@@ -259,6 +259,17 @@ class CpuOps:
         a = alpha.reshape(-1, 1)
         out.copy_(a * real + (1 - a) * fake)
 
+    def critic_inputs(self, out, lab_out, real, fake, alpha, real_lab, fake_lab):
+        M = real.shape[0]
+        a = alpha.reshape(-1, 1)
+        out[:M].copy_(real)
+        out[M:2 * M].copy_(fake)
+        out[2 * M:].copy_(a * real + (1 - a) * fake)
+        if lab_out is not None:
+            lab_out[:M].copy_(real_lab)
+            lab_out[M:2 * M].copy_(fake_lab)
+            lab_out[2 * M:].copy_(fake_lab)
+
     def gp_penalty(self, V, rowpen, UX, lambda_gp):
         M = UX.shape[0]
         n = UX.norm(2, dim=1)

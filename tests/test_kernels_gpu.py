@@ -410,6 +410,23 @@ def test_reparam_libsize_gp(ops):
     ops.gp_interp(o, dev(real), dev(fake), dev(alpha))
     cpu.gp_interp(eo, real, fake, alpha)
     close(o, eo, 1e-6)
+    # the critic step's stacked input (real | generated | interpolated rows and their labels) in one launch, written
+    # into a view of a wider buffer, with and without labels
+    for n_cov in (0, 1, 2):
+        wide = torch.full((3 * M, G + 12), -7.0).cuda()
+        ewide = torch.full((3 * M, G + 12), -7.0)
+        lab = elab = rl = fl = None
+        if n_cov:
+            gen = torch.Generator().manual_seed(10)
+            rl, fl = torch.randint(0, 12, (M, n_cov), generator=gen), torch.randint(0, 12, (M, n_cov), generator=gen)
+            lab, elab = torch.full((3 * M, n_cov), -1).cuda(), torch.full((3 * M, n_cov), -1)
+        ops.critic_inputs(wide[:, :G], lab, dev(real), dev(fake), dev(alpha), dev(rl) if n_cov else None,
+                          dev(fl) if n_cov else None)
+        cpu.critic_inputs(ewide[:, :G], elab, real, fake, alpha, rl, fl)
+        assert torch.equal(wide.cpu()[:2 * M], ewide[:2 * M]) and torch.equal(wide.cpu()[:, G:], ewide[:, G:])
+        close(wide[2 * M:, :G], ewide[2 * M:, :G], 1e-6)
+        if n_cov:
+            assert torch.equal(lab.cpu(), elab)
     V, rp, eV, erp = torch.empty(M, G).cuda(), torch.empty(M).cuda(), torch.empty(M, G), torch.empty(M)
     ux = rnd(M, G, seed=9) * 0.05
     ops.gp_penalty(V, rp, dev(ux), 13.0)
