@@ -171,6 +171,19 @@ if "uploads" in variant:
     StepEngine.state_dict = _upl_state_dict
 first_upl = {}
 
+# "keepgraphs": the HIP graphs of every engine stay alive until the process ends (is it their destruction that matters?)
+kept = []
+_enable_graphs = StepEngine.enable_graphs
+
+
+def _enable_graphs_keep(self):
+    _enable_graphs(self)
+    kept.append(self._graphs)
+
+
+if "keepgraphs" in variant:
+    StepEngine.enable_graphs = _enable_graphs_keep
+
 # every product issued twice (outside graph capture) and the two results compared on the device: a product that is
 # not a pure function of its operands shows here, with its shape
 from cycle_gan_rna_amd.ops import HipOps  # noqa: E402
