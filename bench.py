@@ -151,7 +151,15 @@ def main():
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ.get("CGRNA_BENCH_WATCHDOG", "600")), exit=True)
     torch.cuda.set_device(local)
-    if world > 1:
+    # CGRNA_DDP_ONE_RANK=1: a process group of one rank and the several-rank schedule (RCCL calls between the parts of
+    # a step), to exercise that path on a one-GPU machine
+    one_rank_group = world == 1 and bool(os.environ.get("CGRNA_DDP_ONE_RANK"))
+    if one_rank_group:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or one_rank_group:
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local))
         else:
@@ -179,7 +187,7 @@ def main():
     if not a.eager:
         eng.enable_graphs()
 
-    lookahead = not (a.sequential or a.only or a.no_lookahead or world > 1)
+    lookahead = not (a.sequential or a.only or a.no_lookahead or world > 1 or one_rank_group)
     if lookahead:
         eng.enable_lookahead()
 
@@ -352,7 +360,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu, "bf16_mfma": other, "step_parts": parts,
         }
         print(json.dumps(line))
-    if world > 1:
+    if world > 1 or one_rank_group:
         dist.destroy_process_group()
 
 

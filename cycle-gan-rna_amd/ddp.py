@@ -14,13 +14,18 @@ The reference has no distributed code; the conventions chosen here:
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
 
 class GradSync:
     def __init__(self, device, bucket_bytes=64 << 20):
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        # CGRNA_DDP_ONE_RANK: take the several-rank code path (collectives between the parts of a step) with a process
+        # group of one rank - the way to run that path over RCCL on a machine with one GPU
+        self.enabled = dist.is_available() and dist.is_initialized() and \
+            (dist.get_world_size() > 1 or bool(os.environ.get("CGRNA_DDP_ONE_RANK")))
         self.world = dist.get_world_size() if self.enabled else 1
         self.device = torch.device(device)
         self.is_cuda = self.device.type == "cuda"

@@ -788,9 +788,7 @@ class EngineBase:
         streams.  They are independent between a few join points, and most kernels of one half
         leave much of the chip idle at batch 512, so the halves overlap.  Only for noise that is
         drawn on the device: the order of draws then differs from the reference's call order."""
-        self.sides = [torch.cuda.Stream(device=self.ops.device) for _ in range(3)]
-        for st in self.sides:
-            self.ops.prepare_stream(st)
+        self.sides = [self.ops.stream(f"side{i}") for i in range(3)]
         self.ops.prepare_stream(torch.cuda.current_stream(self.ops.device))
         self.concurrent = True
 
@@ -913,8 +911,7 @@ class EngineBase:
             # scratch by stream, and graphs of different lanes are replayed side by side
             lane = "ahead" if self._lane_sides is not None else "main"
             if lane not in self._cap_streams:
-                self._cap_streams[lane] = torch.cuda.Stream(device=self.ops.device)
-                self.ops.prepare_stream(self._cap_streams[lane])
+                self._cap_streams[lane] = self.ops.stream("capture-" + lane)
             # thread-local capture mode: helper threads of the process (a collective backend's progress thread, for
             # one) may keep making HIP calls while this thread captures
             # no garbage collection while capturing: destroying a dead object that owns HIP resources (an old graph,
@@ -1413,11 +1410,8 @@ class StepEngine(EngineBase):
         same noise.  The critic step's forwards alternate between two workspaces, because one is still being read
         by the critics when the next is written."""
         assert self.concurrent, "enable_concurrency() first"
-        dev = self.ops.device
-        self.ahead = torch.cuda.Stream(device=dev)
-        self.ahead_sides = [torch.cuda.Stream(device=dev)]
-        for st in [self.ahead] + self.ahead_sides:
-            self.ops.prepare_stream(st)
+        self.ahead = self.ops.stream("ahead")
+        self.ahead_sides = [self.ops.stream("ahead-side0")]
         N, B = self.nets, self.max_b
         gm, gh = self.g_mouse, self.g_human
         self.gen_d = [{"g_m2h": GenPass(self, N["g_m2h"], gm, gh, B), "g_h2m": GenPass(self, N["g_h2m"], gh, gm, B)}

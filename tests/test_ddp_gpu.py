@@ -170,3 +170,17 @@ def test_bench_starts_its_own_ranks():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="1"),
                        cwd=ROOT, capture_output=True, text=True, timeout=100)
     assert p.returncode != 0 and "WORLD_SIZE" in p.stderr
+
+
+def test_several_rank_schedule_over_rccl_with_one_rank():
+    """The schedule of a several-rank job (every device part of a step its own HIP graph, the gradient and loss-sum
+    collectives issued between the replays on the communication stream, the critics' update deferred) over RCCL
+    itself: a process group of one rank on the test GPU (CGRNA_DDP_ONE_RANK).  With one rank averaging changes
+    nothing, so the step must run to finite losses at the quoted size, with graphs and eagerly."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(CGRNA_DDP_ONE_RANK="1", MASTER_PORT="29541")
+    for extra in ([], ["--eager"]):
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--no-roofline",
+               "--no-cpu-baseline", "--no-bf16-line"] + extra
+        out = _bench_line(cmd, env, 200)
+        assert out["n_gpus"] == 1 and out["value"] > 0
