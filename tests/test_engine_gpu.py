@@ -450,3 +450,43 @@ def test_engine_called_from_another_stream(ops):
                 d, g = _seven_iterations(ops, nets, cfg, cm, ch, dx, *m)
                 assert torch.equal(d, base[m][0]) and torch.equal(g, base[m][1]), m
     torch.cuda.synchronize()
+
+
+def test_engines_share_streams_and_scratch(ops):
+    """Engines built one after the other (and two alive at once, stepping in turn) run their branches on the same
+    side streams with the same scratch: device memory reserved by the process does not grow with the number of
+    engines built, and interleaving two engines changes neither's results."""
+    from cycle_gan_rna_amd.engine import StepEngine
+    from cycle_gan_rna_amd.noise import DeviceNoise
+    cfg = small_cfg(preprocess_type="log_normalized", nb_critic=2)
+    nets, xm, xh, lm, lh = make_problem(64, 64, 32, cfg)
+    cm, ch = O.centroid_table(xm, lm, 12), O.centroid_table(xh, lh, 12)
+    dx = [t.cuda() for t in (xm, xh, lm[:, None], lh[:, None])]
+    base = _seven_iterations(ops, nets, cfg, cm, ch, dx, True, True)
+    assert ops.stream("side0") is ops.stream("side0")
+    torch.cuda.synchronize()
+    reserved = torch.cuda.memory_reserved()
+    for _ in range(6):
+        d, g = _seven_iterations(ops, nets, cfg, cm, ch, dx, True, True)
+        assert torch.equal(d, base[0]) and torch.equal(g, base[1])
+    torch.cuda.synchronize()
+    assert torch.cuda.memory_reserved() <= reserved + (64 << 20)
+    # two engines alive, one iteration of each in turn, on the shared streams
+    engs, noises = [], []
+    for _ in range(2):
+        e = StepEngine(nets, cfg, cm, ch, ops, 32)
+        e.enable_concurrency()
+        e.enable_lookahead()           # eager launches: a generator of its own per engine cannot be captured
+        engs.append(e)
+        noises.append(DeviceNoise(ops.device, seed=7, default_generator=False))
+    solo = StepEngine(nets, cfg, cm, ch, ops, 32)
+    solo_noise = DeviceNoise(ops.device, seed=7, default_generator=False)
+    for i in range(7):
+        for e, n in zip(engs, noises):
+            n.begin_step()
+            e.iteration(i, *dx, n)
+        solo_noise.begin_step()
+        solo.iteration(i, *dx, solo_noise)
+    torch.cuda.synchronize()
+    for e in engs:
+        assert torch.equal(e.arena_d.p, solo.arena_d.p) and torch.equal(e.arena_g.p, solo.arena_g.p)
