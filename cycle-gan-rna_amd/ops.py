@@ -81,17 +81,19 @@ class HipOps:
             self._scratch[key] = ws
         return ws
 
-    def stream(self, role):
-        """The side stream of this device with the given role ("side0", "ahead", "capture-main" ...), made at first
-        use with its scratch and kept for the life of the process: every engine built on these ops runs its branches
-        on the same few streams.  (A fresh torch.cuda.Stream per engine walks through torch's pool of 32 streams, and
-        each new handle would get scratch of its own and allocator pools of its own.)"""
+    def stream(self, role, scratch=True):
+        """The side stream of this device with the given role ("side0", "ahead", "capture-main", "comm" ...), made at
+        first use (with scratch for the kernels launched on it, unless scratch=False) and kept for the life of the
+        process: every engine built on these ops runs its branches on the same few streams.  (A fresh
+        torch.cuda.Stream per engine walks through torch's pool of 32 streams, and each new handle would get scratch
+        of its own and allocator pools of its own.)"""
         if not hasattr(self, "_streams"):
             self._streams = {}
         st = self._streams.get(role)
         if st is None:
             st = self._streams[role] = torch.cuda.Stream(device=self.device)
-            self.prepare_stream(st)
+            if scratch:
+                self.prepare_stream(st)
         return st
 
     def prepare_stream(self, stream):
