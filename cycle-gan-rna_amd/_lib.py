@@ -28,6 +28,9 @@ class GlossDesc(C.Structure):
 SIGNATURES = {
     "cg_version": ([], I),
     "cg_gemm": ([P, I, P, I, P, I, I, I, I, I, I, I, P, I, P, I, P, I, F, I, P, Z, P], I),
+    "cg_gemm_slabs": ([P, I, P, I, P, I, I, I, I, I, I, I, P, P, Z, P, P], I),
+    "cg_bn_fwd_slabs_ok": ([I, I], I),
+    "cg_bn_fwd_slabs": ([P, I, P, I, P, I, P, I, I, P, P, F, P, P, P, P, F, F, P, I, P, I, P], I),
     "cg_bn_workspace_bytes": ([I, I], Z),
     "cg_bn_fwd": ([P, I, P, I, I, I, P, P, F, P, P, P, P, F, F, P, I, P, I, P, I, P, Z, P], I),
     "cg_bn_fwd_static": ([P, I, P, I, I, I, P, P, F, P, P, P, P, F, F, P, I, P, I, P, I, P], I),

@@ -253,12 +253,16 @@ __device__ __forceinline__ void strip_reduce_f(double (&s)[NS], double* lds /* N
   }
 }
 
-template <int CWF, int NR>
-__global__ void __launch_bounds__(256) bn_fwd_fused(float* Y, int ldy, const float* X, int ldx, int M, int N,
+// SLABS: the input is not in X yet but in `nslab` split-K partial sums of the product that makes it (dense M x N
+// slabs, one after the other) plus the product's bias; they are added in slab order, as splitk_reduce_kernel of
+// gemm.hip adds them, and the sum is also written to X (the backward pass reads it).
+template <int CWF, int NR, bool SLABS>
+__global__ void __launch_bounds__(256) bn_fwd_fused(float* Y, int ldy, float* X, int ldx, int M, int N,
                                                     const float* gamma, const float* beta, float eps, float* mean_out,
                                                     float* invstd_out, float* rmean, float* rvar, float momentum,
                                                     float slope, const float* mask, int ldmask, float* pm_out, int ldpm,
-                                                    u16* ybf, int ldybf) {
+                                                    u16* ybf, int ldybf, const float* slabs, int nslab,
+                                                    const float* xbias) {
   constexpr int LANES = 256 / CWF;
   __shared__ double lds[2 * 256];
   const int c = threadIdx.x % CWF, r0 = threadIdx.x / CWF, col = blockIdx.x * CWF + c;
@@ -267,8 +271,19 @@ __global__ void __launch_bounds__(256) bn_fwd_fused(float* Y, int ldy, const flo
   // around a load makes the compiler wait for each load before issuing the next
   const int colc = min(col, N - 1);
   float x[NR];
+  if (!SLABS) {
 #pragma unroll
-  for (int i = 0; i < NR; ++i) x[i] = X[(size_t)min(r0 + i * LANES, M - 1) * ldx + colc];
+    for (int i = 0; i < NR; ++i) x[i] = X[(size_t)min(r0 + i * LANES, M - 1) * ldx + colc];
+  } else {
+    const float bv = xbias ? xbias[colc] : 0.f;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) x[i] = bv;
+    for (int k = 0; k < nslab; ++k) {
+      const float* sl = slabs + (size_t)k * M * N;
+#pragma unroll
+      for (int i = 0; i < NR; ++i) x[i] += sl[(size_t)min(r0 + i * LANES, M - 1) * N + colc];
+    }
+  }
   double s[2] = {0.0, 0.0};
 #pragma unroll
   for (int i = 0; i < NR; ++i) {
@@ -296,6 +311,7 @@ __global__ void __launch_bounds__(256) bn_fwd_fused(float* Y, int ldy, const flo
   for (int i = 0; i < NR; ++i) {
     const int m = r0 + i * LANES;
     if (m >= M) break;
+    if (SLABS) X[(size_t)m * ldx + col] = x[i];
     const float h = (x[i] - mean) * invstd * ga + be;
     float pm = h > 0.f ? 1.f : slope;
     if (mask) pm *= mask[(size_t)m * ldmask + col];
@@ -429,9 +445,10 @@ extern "C" int cg_bn_fwd_seg(float* Y, int ldy, const float* X, int ldx, int seg
   if (!workspace || workspace_bytes < nseg * cg_bn_workspace_bytes(M, N)) return CG_ERR_WORKSPACE;
   if (nseg == 1 && M <= 512 && N >= 256) {      // one launch (see bn_fwd_fused), 32 rows per thread
 #define CG_BN_FWD_FUSED(CWF, NR)                                                                                    \
-  hipLaunchKernelGGL((bn_fwd_fused<CWF, NR>), dim3((N + CWF - 1) / CWF), dim3(256), 0, (hipStream_t)stream, Y, ldy,  \
-                     X, ldx, M, N, gamma, beta, eps, mean_out, invstd_out, running_mean, running_var, momentum,      \
-                     slope, mask, ldmask, pm_out, ldpm, (u16*)ybf16, ldybf16)
+  hipLaunchKernelGGL((bn_fwd_fused<CWF, NR, false>), dim3((N + CWF - 1) / CWF), dim3(256), 0, (hipStream_t)stream,   \
+                     Y, ldy, const_cast<float*>(X), ldx, M, N, gamma, beta, eps, mean_out, invstd_out, running_mean, \
+                     running_var, momentum, slope, mask, ldmask, pm_out, ldpm, (u16*)ybf16, ldybf16,                 \
+                     (const float*)nullptr, 0, (const float*)nullptr)
     CG_BN_FWD_FUSED(16, 32);      // measured: 7 us at 512 x 512..2048 (strips of 32 columns, 64 rows per thread: 12 us)
 #undef CG_BN_FWD_FUSED
     return cg_launch_status();
@@ -452,6 +469,23 @@ extern "C" int cg_bn_fwd(float* Y, int ldy, const float* X, int ldx, int M, int 
                          void* stream) {
   return cg_bn_fwd_seg(Y, ldy, X, ldx, M, 1, 0u, N, gamma, beta, eps, mean_out, invstd_out, running_mean, running_var,
                        momentum, slope, mask, ldmask, pm_out, ldpm, ybf16, ldybf16, workspace, workspace_bytes, stream);
+}
+
+extern "C" int cg_bn_fwd_slabs_ok(int M, int N) { return M > 0 && M <= 512 && N >= 256; }
+
+extern "C" int cg_bn_fwd_slabs(float* Y, int ldy, float* X, int ldx, const float* slabs, int n_slabs,
+                               const float* x_bias, int M, int N, const float* gamma, const float* beta, float eps,
+                               float* mean_out, float* invstd_out, float* running_mean, float* running_var,
+                               float momentum, float slope, const float* mask, int ldmask, float* pm_out, int ldpm,
+                               void* stream) {
+  if (!Y || !X || !slabs || !gamma || !beta || !mean_out || !invstd_out || M <= 0 || N <= 0 || n_slabs < 1)
+    return CG_ERR_BAD_ARG;
+  if (ldy < N || ldx < N || (mask && ldmask < N) || (pm_out && ldpm < N)) return CG_ERR_BAD_ARG;
+  if (!cg_bn_fwd_slabs_ok(M, N)) return CG_ERR_UNSUPPORTED;      // only the one-launch form reads slabs
+  hipLaunchKernelGGL((bn_fwd_fused<16, 32, true>), dim3((N + 15) / 16), dim3(256), 0, (hipStream_t)stream, Y, ldy, X,
+                     ldx, M, N, gamma, beta, eps, mean_out, invstd_out, running_mean, running_var, momentum, slope, mask,
+                     ldmask, pm_out, ldpm, (u16*)nullptr, 0, slabs, n_slabs, x_bias);
+  return cg_launch_status();
 }
 
 // Device address of `scratch` on the current device, looked up once per device.

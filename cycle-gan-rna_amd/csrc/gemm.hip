@@ -976,8 +976,9 @@ void launch_splitk_reduce(const GemmArgs& g, int splits, hipStream_t st) {
   else hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(blocks), dim3(256), 0, st, g, splits);
 }
 
+// keep != nullptr: the caller combines the split-K slabs itself (cg_gemm_slabs): no reduce launch, *keep = slabs
 template <int BM, int BN, bool HALF = false, bool AH = false, bool BH = false>
-int launch_f32(const GemmArgs& g, int transA, int transB, bool vec, hipStream_t st, int splits = 1) {
+int launch_f32(const GemmArgs& g, int transA, int transB, bool vec, hipStream_t st, int splits = 1, int* keep = nullptr) {
   GemmArgs a = g;
   const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
   a.tiles_n = tn;
@@ -1002,7 +1003,8 @@ int launch_f32(const GemmArgs& g, int transA, int transB, bool vec, hipStream_t 
   else if (transA && !transB) CG_LAUNCH(true, false);
   else CG_LAUNCH(true, true);
 #undef CG_LAUNCH
-  if (splits > 1) launch_splitk_reduce(g, splits, st);
+  if (keep) *keep = splits;
+  else if (splits > 1) launch_splitk_reduce(g, splits, st);
   return cg_launch_status();
 }
 
@@ -1029,7 +1031,7 @@ CG_DMA_INST(64, 64)
 #undef CG_DMA_INST
 
 template <int BM, int BN>
-int launch_f32_dma(const GemmArgs& g, int transA, int transB, hipStream_t st, int splits) {
+int launch_f32_dma(const GemmArgs& g, int transA, int transB, hipStream_t st, int splits, int* keep) {
   GemmArgs a = g;
   const int tm = (g.M + BM - 1) / BM, tn = (g.N + BN - 1) / BN;
   a.tiles_n = tn;
@@ -1042,16 +1044,15 @@ int launch_f32_dma(const GemmArgs& g, int transA, int transB, hipStream_t st, in
   else if (!transA && !transB) hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, false, false, KW, S>), grid, block, 0, st, a);
   else if (transA && !transB) hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, true, false, KW, S>), grid, block, 0, st, a);
   else hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, true, true, KW, S>), grid, block, 0, st, a);
-  if (splits > 1) launch_splitk_reduce(g, splits, st);
+  if (keep) *keep = splits;
+  else if (splits > 1) launch_splitk_reduce(g, splits, st);
   return cg_launch_status();
 }
 
-}  // namespace
-
-extern "C" int cg_gemm(float* C, int ldc, const void* A, int lda, const void* B, int ldb,
-                       int M, int N, int K, int transA, int transB, int dtype,
-                       const float* bias, int epi, const float* E, int lde, float* aux, int ldaux,
-                       float slope, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+int gemm_dispatch(float* C, int ldc, const void* A, int lda, const void* B, int ldb,
+                  int M, int N, int K, int transA, int transB, int dtype,
+                  const float* bias, int epi, const float* E, int lde, float* aux, int ldaux,
+                  float slope, int accumulate, void* workspace, size_t workspace_bytes, void* stream, int* keep) {
   if (!C || !A || !B || M < 0 || N < 0 || K < 0) return CG_ERR_BAD_ARG;
   if (M == 0 || N == 0) return CG_OK;
   if (K == 0) return CG_ERR_BAD_ARG;      // an empty sum has no tile to launch; callers never need it
@@ -1077,7 +1078,10 @@ extern "C" int cg_gemm(float* C, int ldc, const void* A, int lda, const void* B,
              epi, accumulate, slope, 0, 1 << 30, (float*)workspace, (unsigned)a_bytes, (unsigned)b_bytes};
   const bool tiny = K <= 16 || N <= 2 || (M <= 2 && transA && !transB);
   if (tiny && (ah || bh)) return CG_ERR_UNSUPPORTED;      // the plain-FMA kernels read float32
-  if (tiny && launch_small(g, transA, transB, st)) return cg_launch_status();
+  if (tiny && launch_small(g, transA, transB, st)) {
+    if (keep) *keep = 1;
+    return cg_launch_status();
+  }
   // 16-byte loads of the float32 operands (a bf16 operand has its own conditions, checked above)
   const bool vec = (ah || ((uintptr_t)A % 16 == 0 && lda % 4 == 0)) && (bh || ((uintptr_t)B % 16 == 0 && ldb % 4 == 0));
   // Tile and split-K choice by a cost model fitted to a sweep of the step's shapes on MI355X (microseconds).
@@ -1146,16 +1150,16 @@ extern "C" int cg_gemm(float* C, int ldc, const void* A, int lda, const void* B,
   const bool dma = !half && vec && (transA ? M % 4 == 0 : K % 4 == 0) && (transB ? K % 4 == 0 : N % 4 == 0) &&
                    !(tuning && getenv("CGRNA_GEMM_NO_DMA"));
   if (dma) {
-    if (best == 0) return launch_f32_dma<128, 128>(g, transA, transB, st, best_splits);
-    if (best == 1) return launch_f32_dma<128, 64>(g, transA, transB, st, best_splits);
-    return launch_f32_dma<64, 64>(g, transA, transB, st, best_splits);
+    if (best == 0) return launch_f32_dma<128, 128>(g, transA, transB, st, best_splits, keep);
+    if (best == 1) return launch_f32_dma<128, 64>(g, transA, transB, st, best_splits, keep);
+    return launch_f32_dma<64, 64>(g, transA, transB, st, best_splits, keep);
   }
   if (half) {
 #define CG_HALF_TILES(AH, BH)                                                                            \
   do {                                                                                                   \
-    if (best == 0) return launch_f32<128, 128, true, AH, BH>(g, transA, transB, vec, st, best_splits);   \
-    if (best == 1) return launch_f32<128, 64, true, AH, BH>(g, transA, transB, vec, st, best_splits);    \
-    return launch_f32<64, 64, true, AH, BH>(g, transA, transB, vec, st, best_splits);                    \
+    if (best == 0) return launch_f32<128, 128, true, AH, BH>(g, transA, transB, vec, st, best_splits, keep);   \
+    if (best == 1) return launch_f32<128, 64, true, AH, BH>(g, transA, transB, vec, st, best_splits, keep);    \
+    return launch_f32<64, 64, true, AH, BH>(g, transA, transB, vec, st, best_splits, keep);                    \
   } while (0)
     if ((ah || bh) && !vec) return CG_ERR_UNSUPPORTED;     // the float32 partner of a bf16 operand must allow 16-byte loads
     if (ah && bh) CG_HALF_TILES(true, true);
@@ -1164,7 +1168,27 @@ extern "C" int cg_gemm(float* C, int ldc, const void* A, int lda, const void* B,
     CG_HALF_TILES(false, false);
 #undef CG_HALF_TILES
   }
-  if (best == 0) return launch_f32<128, 128>(g, transA, transB, vec, st, best_splits);
-  if (best == 1) return launch_f32<128, 64>(g, transA, transB, vec, st, best_splits);
-  return launch_f32<64, 64>(g, transA, transB, vec, st, best_splits);
+  if (best == 0) return launch_f32<128, 128>(g, transA, transB, vec, st, best_splits, keep);
+  if (best == 1) return launch_f32<128, 64>(g, transA, transB, vec, st, best_splits, keep);
+  return launch_f32<64, 64>(g, transA, transB, vec, st, best_splits, keep);
+}
+
+}  // namespace
+
+extern "C" int cg_gemm(float* C, int ldc, const void* A, int lda, const void* B, int ldb,
+                       int M, int N, int K, int transA, int transB, int dtype,
+                       const float* bias, int epi, const float* E, int lde, float* aux, int ldaux,
+                       float slope, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
+  return gemm_dispatch(C, ldc, A, lda, B, ldb, M, N, K, transA, transB, dtype, bias, epi, E, lde, aux, ldaux, slope,
+                       accumulate, workspace, workspace_bytes, stream, nullptr);
+}
+
+extern "C" int cg_gemm_slabs(float* C, int ldc, const void* A, int lda, const void* B, int ldb,
+                             int M, int N, int K, int transA, int transB, int dtype, const float* bias,
+                             void* workspace, size_t workspace_bytes, int* n_slabs, void* stream) {
+  if (!n_slabs) return CG_ERR_BAD_ARG;
+  *n_slabs = 1;
+  if (M == 0 || N == 0) return CG_OK;
+  return gemm_dispatch(C, ldc, A, lda, B, ldb, M, N, K, transA, transB, dtype, bias, CG_EPI_NONE, nullptr, 0, nullptr, 0,
+                       0.f, 0, workspace, workspace_bytes, stream, n_slabs);
 }

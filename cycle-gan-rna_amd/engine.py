@@ -266,9 +266,15 @@ class GenPass:
 
     def _linear_bn_relu(self, out_a, out_h0, stats, a, lin, bn, train):
         ops, P = self.ops, self.net.P
-        ops.gemm(out_h0, a, P[lin + ".weight"], False, True, bias=P[lin + ".bias"])
         gamma, beta, rm, rv = self._bn(bn)
-        if train:
+        # when the product splits K, the BatchNorm adds the partial sums itself while it loads its input: one launch
+        # and one pass over the pre-activation less
+        slabs = train and ops.bn_slabs_ok(*out_h0.shape)
+        n = ops.gemm(out_h0, a, P[lin + ".weight"], False, True, bias=P[lin + ".bias"], keep_slabs=slabs)
+        if slabs and n > 1:
+            ops.bn_fwd_slabs(out_a, out_h0, n, P[lin + ".bias"], gamma, beta, stats[0], stats[1], rm, rv, 0.0)
+            self.net.nbt[bn + ".num_batches_tracked"] += 1
+        elif train:
             ops.bn_fwd(out_a, out_h0, gamma, beta, stats[0], stats[1], rm, rv, 0.0)
             self.net.nbt[bn + ".num_batches_tracked"] += 1
         else:

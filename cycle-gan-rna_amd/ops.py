@@ -164,7 +164,9 @@ class HipOps:
 
     # -- GEMM -----------------------------------------------------------------
     def gemm(self, Cm, A, B, transA=False, transB=False, bias=None, epi=EPI_NONE, E=None, aux=None, slope=0.0,
-             accumulate=False, dtype=None):
+             accumulate=False, dtype=None, keep_slabs=False):
+        """keep_slabs (no epilogue, no accumulation): if the product splits K, leave the partial sums in this
+        stream's scratch for the consumer to add (bn_fwd_slabs) and return their number; 1 = Cm holds the result."""
         _chk(Cm), _chk(A), _chk(B)
         M, N = Cm.shape
         K = A.shape[0] if transA else A.shape[1]
@@ -193,9 +195,17 @@ class HipOps:
         if self._gemm_events is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(torch.cuda.current_stream(self.device))
-        st = self.lib.cg_gemm(_ptr(Cm), _ld(Cm), pA, _ld(A), pB, _ld(B), M, N, K, int(transA), int(transB),
-                              dtype, _ptr(bias), epi, _ptr(E), _ld(E), _ptr(aux), _ld(aux), float(slope),
-                              int(accumulate), _ptr(self._ws()[0]), self._ws()[0].numel() * 4, self._stream())
+        n_slabs = None
+        if keep_slabs:
+            assert epi == EPI_NONE and E is None and aux is None and not accumulate
+            n_slabs = C.c_int(1)
+            st = self.lib.cg_gemm_slabs(_ptr(Cm), _ld(Cm), pA, _ld(A), pB, _ld(B), M, N, K, int(transA), int(transB),
+                                        dtype, _ptr(bias), _ptr(self._ws()[0]), self._ws()[0].numel() * 4,
+                                        C.byref(n_slabs), self._stream())
+        else:
+            st = self.lib.cg_gemm(_ptr(Cm), _ld(Cm), pA, _ld(A), pB, _ld(B), M, N, K, int(transA), int(transB),
+                                  dtype, _ptr(bias), epi, _ptr(E), _ld(E), _ptr(aux), _ld(aux), float(slope),
+                                  int(accumulate), _ptr(self._ws()[0]), self._ws()[0].numel() * 4, self._stream())
         if self._gemm_events is not None:
             e1.record(torch.cuda.current_stream(self.device))
             elem = lambda flag: 2.0 if dtype & flag else 4.0  # noqa: E731
@@ -203,6 +213,7 @@ class HipOps:
                                       elem(4) * M * K + elem(2) * K * N + 4.0 * M * N * (2 if accumulate else 1),
                                       (M, N, K, int(transA), int(transB), int(accumulate), dtype)))
         _lib.check(st, "cg_gemm")
+        return n_slabs.value if n_slabs is not None else None
 
     def gemm_untimed(self, *args, **kw):
         """gemm() without event bracketing even while begin_gemm_timing() is active."""
@@ -221,6 +232,23 @@ class HipOps:
                                 _ptr(invstd), _ptr(rmean), _ptr(rvar), momentum, float(slope), _ptr(mask), _ld(mask),
                                 _ptr(pm), _ld(pm), None, 0, *self._bnws(M, N), self._stream())
         _lib.check(st, "cg_bn_fwd")
+
+    def bn_slabs_ok(self, M, N):
+        """Can bn_fwd_slabs take an M x N input?  (Only the one-launch BatchNorm reads slabs.)"""
+        return bool(self.lib.cg_bn_fwd_slabs_ok(M, N))
+
+    def bn_fwd_slabs(self, Y, X, n_slabs, x_bias, gamma, beta, mean, invstd, rmean, rvar, slope, mask=None, pm=None,
+                     eps=1e-5, momentum=0.1):
+        """bn_fwd whose input is still in the n_slabs partial sums that gemm(..., keep_slabs=True) just left in this
+        stream's scratch: X receives bias + slabs, Y the normalised activation."""
+        M, N = X.shape
+        assert Y.shape == X.shape and gamma.numel() == N and mean.numel() == N and invstd.numel() == N
+        ws = self._ws()[0]
+        assert n_slabs >= 1 and n_slabs * M * N <= ws.numel()
+        st = self.lib.cg_bn_fwd_slabs(_ptr(Y), _ld(Y), _ptr(X), _ld(X), _ptr(ws), n_slabs, _ptr(x_bias), M, N,
+                                      _ptr(gamma), _ptr(beta), eps, _ptr(mean), _ptr(invstd), _ptr(rmean), _ptr(rvar),
+                                      momentum, float(slope), _ptr(mask), _ld(mask), _ptr(pm), _ld(pm), self._stream())
+        _lib.check(st, "cg_bn_fwd_slabs")
 
     @staticmethod
     def _order_code(order, nseg):

@@ -95,6 +95,26 @@ int cg_bn_fwd(float* Y, int ldy, const float* X, int ldx, int M, int N,
               void* ybf16, int ldybf16, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * A Linear layer whose output feeds a BatchNorm (GAN_functions.py:89-90, 92-93, 117-118, 120-121: every hidden
+ * layer of the generators) without the pass that combines split-K partial sums: cg_gemm_slabs is cg_gemm without
+ * epilogue and accumulation that, when it splits K, leaves the partial sums in `workspace` as *n_slabs dense
+ * M x N slabs and does not touch C or add the bias (*n_slabs = 1: C holds the finished product with its bias, as
+ * after cg_gemm).  cg_bn_fwd_slabs is cg_bn_fwd whose input is those slabs: it adds bias + slabs in slab order (the
+ * same additions in the same order as cg_gemm makes), writes the sum to X (the backward pass reads it) and the
+ * normalised activation to Y.  Only shapes the one-launch BatchNorm handles (cg_bn_fwd_slabs_ok(M, N) != 0);
+ * the two calls must follow each other on one stream with the same workspace.
+ */
+int cg_gemm_slabs(float* C, int ldc, const void* A, int lda, const void* B, int ldb,
+                  int M, int N, int K, int transA, int transB, int dtype, const float* bias,
+                  void* workspace, size_t workspace_bytes, int* n_slabs, void* stream);
+int cg_bn_fwd_slabs_ok(int M, int N);
+int cg_bn_fwd_slabs(float* Y, int ldy, float* X, int ldx, const float* slabs, int n_slabs, const float* x_bias,
+                    int M, int N, const float* gamma, const float* beta, float eps,
+                    float* mean_out, float* invstd_out, float* running_mean, float* running_var,
+                    float momentum, float slope, const float* mask, int ldmask, float* pm_out, int ldpm,
+                    void* stream);
+
+/*
  * cg_bn_fwd for callers that cannot allocate device memory or hand in a workspace (code under HIP graph capture,
  * tight serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  The per-chunk column
  * sums live in a 1 MiB array inside the library's device image (one copy per GPU, held until the process ends);

@@ -42,7 +42,9 @@ class CpuOps:
 
     # -- GEMM (cg_gemm) -----------------------------------------------------------
     def gemm(self, Cm, A, B, transA=False, transB=False, bias=None, epi=EPI_NONE, E=None, aux=None, slope=0.0,
-             accumulate=False):
+             accumulate=False, keep_slabs=False):
+        """keep_slabs (cg_gemm_slabs): the device may leave split-K partial sums for the consumer; here the product is
+        always finished, which the device reports as one slab."""
         a = A.t() if transA else A
         b = B.t() if transB else B
         h = a @ b
@@ -59,6 +61,19 @@ class CpuOps:
                 aux.copy_(pm)
         else:
             Cm.copy_(h * E)
+        return 1 if keep_slabs else None
+
+    def bn_slabs_ok(self, M, N):
+        return False
+
+    def bn_fwd_slabs(self, Y, X, slabs, x_bias, gamma, beta, mean, invstd, rmean, rvar, slope, mask=None, pm=None,
+                     eps=1e-5, momentum=0.1):
+        """cg_bn_fwd_slabs: X <- bias + the partial sums `slabs` (n, M, N) added in order, then bn_fwd."""
+        h = x_bias.reshape(1, -1).expand_as(X).clone() if x_bias is not None else torch.zeros_like(X)
+        for k in range(slabs.shape[0]):
+            h = h + slabs[k]
+        X.copy_(h)
+        self.bn_fwd(Y, X, gamma, beta, mean, invstd, rmean, rvar, slope, mask, pm, eps, momentum)
 
     # -- BatchNorm (cg_bn_fwd / cg_bn_eval / cg_bn_bwd / cg_bn_bwd_bwd) ------------------
     def bn_fwd(self, Y, X, gamma, beta, mean, invstd, rmean, rvar, slope, mask=None, pm=None, eps=1e-5,

@@ -679,3 +679,44 @@ def test_gemm_small_dimension_kernels(ops, M, N, K, ta, tb, epi, acc):
         h = (A.double().t() if ta else A.double()) @ (B.double().t() if tb else B.double()) + bias.double()
         ok = h.abs() > 1e-4
         assert torch.allclose(gaux.cpu().double()[ok], aux[ok], rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("M,N,K,with_mask", [(512, 512, 1024, False), (512, 1024, 2048, True), (300, 256, 5000, False),
+                                             (512, 2048, 268, False), (37, 260, 4096, True)])
+def test_linear_batchnorm_with_slabs_left_to_the_consumer(ops, M, N, K, with_mask):
+    """cg_gemm_slabs + cg_bn_fwd_slabs (the BatchNorm adds the split-K partial sums while it loads) against cg_gemm +
+    cg_bn_fwd: the same additions in the same order, so pre-activation, activation, statistics and running statistics
+    are equal bit for bit; and against the CPU restatement of the slab sum."""
+    x, w, bias = dev(rnd(M, K, seed=1)), dev(rnd(N, K, seed=2) * 0.05), dev(rnd(N, seed=3))
+    gamma, beta = dev(rnd(N, seed=4).abs() + 0.5), dev(rnd(N, seed=5))
+    mask = dev((torch.rand(M, N, generator=torch.Generator().manual_seed(6)) > 0.3).float() / 0.7) if with_mask else None
+    out = {}
+    for mode in ("plain", "slabs"):
+        h0, y = torch.full((M, N), -3.0).cuda(), torch.empty(M, N).cuda()
+        pm = torch.empty(M, N).cuda() if with_mask else None
+        mean, invstd = torch.empty(N).cuda(), torch.empty(N).cuda()
+        rm, rv = torch.zeros(N).cuda(), torch.ones(N).cuda()
+        if mode == "plain":
+            ops.gemm(h0, x, w, False, True, bias=bias)
+            ops.bn_fwd(y, h0, gamma, beta, mean, invstd, rm, rv, 0.2, mask, pm)
+            n = None
+        else:
+            assert ops.bn_slabs_ok(M, N)
+            n = ops.gemm(h0, x, w, False, True, bias=bias, keep_slabs=True)
+            if n > 1:
+                slabs = ops._ws()[0][:n * M * N].view(n, M, N).clone()
+                assert float(h0.min()) == -3.0 and float(h0.max()) == -3.0          # untouched until the consumer runs
+                ops.bn_fwd_slabs(y, h0, n, bias, gamma, beta, mean, invstd, rm, rv, 0.2, mask, pm)
+                eh0, ey = torch.empty(M, N), torch.empty(M, N)
+                cpu.bn_fwd_slabs(ey, eh0, slabs.cpu(), bias.cpu(), gamma.cpu(), beta.cpu(), torch.empty(N), torch.empty(N),
+                                 None, None, 0.2, None if mask is None else mask.cpu())
+                assert torch.equal(h0.cpu(), eh0)
+                close(y, ey, 2e-5)
+            else:
+                ops.bn_fwd(y, h0, gamma, beta, mean, invstd, rm, rv, 0.2, mask, pm)
+        out[mode] = (h0, y, mean, invstd, rm, rv, pm, n)
+    for a, b in zip(out["plain"][:7], out["slabs"][:7]):
+        assert (a is None and b is None) or torch.equal(a, b)
+    if K >= 1024 and M * N <= 512 * 1024:
+        assert out["slabs"][7] > 1, "expected this shape to split K (otherwise the test does not reach the slab path)"
+    assert not ops.bn_slabs_ok(513, 512) and not ops.bn_slabs_ok(512, 128)
