@@ -31,6 +31,7 @@ SIGNATURES = {
     "cg_gemm_slabs": ([P, I, P, I, P, I, I, I, I, I, I, I, P, P, Z, P, P], I),
     "cg_bn_fwd_slabs_ok": ([I, I], I),
     "cg_bn_fwd_slabs": ([P, I, P, I, P, I, P, I, I, P, P, F, P, P, P, P, F, F, P, I, P, I, P], I),
+    "cg_interp_hidden": ([P, I, P, P, I, I, P, I, I, I, P], I),
     "cg_bn_workspace_bytes": ([I, I], Z),
     "cg_bn_fwd": ([P, I, P, I, I, I, P, P, F, P, P, P, P, F, F, P, I, P, I, P, I, P, Z, P], I),
     "cg_bn_fwd_static": ([P, I, P, I, I, I, P, P, F, P, P, P, P, F, F, P, I, P, I, P, I, P], I),

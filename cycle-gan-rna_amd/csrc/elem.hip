@@ -173,6 +173,25 @@ __global__ void critic_inputs_kernel(float* out, int ldo, const float* real, int
   }
 }
 
+// First hidden layer of the critic on the interpolated batch without a product: the layer is linear, so with
+// x_i = a x_r + (1 - a) x_f and the generated batch's embedding on the interpolates,
+//   h_i = a h_r + (1 - a) h_f + a (emb_f - emb_r) We^T        (bias included in h_r, h_f and h_i)
+// H holds h_r in rows [0, M), h_f in [M, 2M) and receives h_i in [2M, 3M); We is stored [N][E].
+__global__ void interp_hidden_kernel(float* H, int ldh, const float* alpha, const float* emb, int lde, int E,
+                                     const float* We, int ldw, int M, int N) {
+  CG_2D_LOOP(M, N) {
+    const float a = alpha[m];
+    float v = a * H[(size_t)m * ldh + col] + (1.f - a) * H[(size_t)(M + m) * ldh + col];
+    if (emb) {
+      float d = 0.f;
+      for (int j = 0; j < E; ++j)
+        d += (emb[(size_t)(M + m) * lde + j] - emb[(size_t)m * lde + j]) * We[(size_t)col * ldw + j];
+      v += a * d;
+    }
+    H[(size_t)(2 * M + m) * ldh + col] = v;
+  }
+}
+
 __global__ void __launch_bounds__(256) gp_penalty_kernel(float* V, int ldv, float* rowpen, const float* UX, int ldu,
                                                          float lam2_over_m, int G) {
   __shared__ float lds[17];
@@ -531,6 +550,15 @@ extern "C" int cg_critic_inputs(float* out, int ldo, const float* real, int ldr,
   Grid2 g = grid2(M, G);
   hipLaunchKernelGGL(critic_inputs_kernel, g.grid, g.block, 0, ST, out, ldo, real, ldr, fake, ldf, alpha, M, G, lab_out,
                      real_lab, fake_lab, n_cov);
+  return cg_launch_status();
+}
+
+extern "C" int cg_interp_hidden(float* H, int ldh, const float* alpha, const float* emb, int lde, int E,
+                                const float* We, int ldw, int M, int N, void* stream) {
+  if (!H || !alpha || M <= 0 || N <= 0 || ldh < N) return CG_ERR_BAD_ARG;
+  if (emb && (!We || E <= 0 || lde < E || ldw < E)) return CG_ERR_BAD_ARG;
+  Grid2 g = grid2(M, N);
+  hipLaunchKernelGGL(interp_hidden_kernel, g.grid, g.block, 0, ST, H, ldh, alpha, emb, lde, E, We, ldw, M, N);
   return cg_launch_status();
 }
 

@@ -25,6 +25,7 @@ from __future__ import annotations
 
 import gc
 import math
+import os
 import weakref
 from collections import OrderedDict
 from typing import Dict, Optional
@@ -653,9 +654,13 @@ class CriticStack:
         if labels is not None:
             self.lab[i * b:(i + 1) * b].copy_(labels)
 
-    def forward(self, b, m1, m2, order):
+    def forward(self, b, m1, m2, order, interp=None):
         """m1 (nseg*b, 1024), m2 (nseg*b, 512): dropout keep masks.  Returns validity (nseg*b, 1) and the features
-        (nseg*b, 256), segment-major."""
+        (nseg*b, 256), segment-major.
+        interp (three input batches only): the per-row alpha with which the third input batch was interpolated from
+        the first two (GAN_functions.py:196-199, with the second batch's labels).  The first layer is linear, so its
+        output on the third batch is then combined from its outputs on the first two instead of being multiplied
+        out again - a third of the layer's product, the largest of the critic step."""
         ops, P, Bf, Gd, S, nx = self.ops, self.net.P, self.net.B, self.Gd, self.S, self.nx
         self.b = b
         R, Rx, off = S * b, nx * b, (S - nx) * b
@@ -666,7 +671,13 @@ class CriticStack:
         else:
             emb.zero_()
         h0 = self.h0[:R]
-        ops.gemm(h0[off:], self.xe[:Rx, :self.W], W1, False, True, bias=P["model.0.bias"])
+        if interp is not None:
+            assert S == 3 and nx == 3
+            ops.gemm(h0[:2 * b], self.xe[:2 * b, :self.W], W1, False, True, bias=P["model.0.bias"])
+            ops.interp_hidden(h0, b, interp, emb if self.have_labels else None,
+                              W1[:, Gd:self.W] if self.have_labels else None)
+        else:
+            ops.gemm(h0[off:], self.xe[:Rx, :self.W], W1, False, True, bias=P["model.0.bias"])
         for k in range(S - nx):
             h0[k * b:(k + 1) * b].copy_(h0[off:off + b])
         ops.bn_fwd_seg(self.a1[:R], h0, S, order, P["model.1.weight"], P["model.1.bias"], self.stats[0], self.stats[1],
@@ -1122,6 +1133,10 @@ class StepEngine(EngineBase):
         self._two(lambda: gen("g_m2h", mouse, mouse_cat), lambda: gen("g_h2m", human, human_cat))
         self._d_state = (mouse, human, mouse_cat, human_cat, noise, out["g_m2h"], out["g_h2m"])
 
+    # the critic's first layer on the interpolates from its outputs on the real and the generated batch (see
+    # CriticStack.forward); False: multiplied out, as the reference does
+    interp_by_linearity = not os.environ.get("CGRNA_INTERP_MULTIPLIED_OUT")
+
     def _d_critics(self):
         ops, cfg = self.ops, self.cfg
         mouse, human, mouse_cat, human_cat, noise, fake_human, fake_mouse = self._d_state
@@ -1138,7 +1153,7 @@ class StepEngine(EngineBase):
             ops.critic_inputs(ds.x[:3 * b], ds.lab[:3 * b] if ds.have_labels else None, real, fake, alpha,
                               real_lab.contiguous() if ds.have_labels else None,
                               fake_lab.contiguous() if ds.have_labels else None)
-            val, _ = ds.forward(b, m1, m2, (0, 1, 2))
+            val, _ = ds.forward(b, m1, m2, (0, 1, 2), interp=alpha if self.interp_by_linearity else None)
             ops.reduce_sum(self.red, s0, val[:b])
             ops.reduce_sum(self.red, s0 + 1, val[b:2 * b])
         self._many(lambda: critic_fwd("d_m", mouse, mouse_cat, fake_mouse, human_cat, S_DM_REAL),

@@ -383,6 +383,19 @@ class HipOps:
                                        G, _ptr(lab_out), _ptr(real_lab), _ptr(fake_lab), n_cov, self._stream())
         _lib.check(st, "cg_critic_inputs")
 
+    def interp_hidden(self, H, M, alpha, emb, We):
+        """H[2M:3M] <- alpha H[:M] + (1 - alpha) H[M:2M] + alpha (emb[M:2M] - emb[:M]) We^T: the critic's first layer
+        on the interpolates from its outputs on the real and the generated batch (emb, We None: no covariates)."""
+        N = H.shape[1]
+        assert H.shape[0] >= 3 * M and alpha.numel() == M
+        E = 0
+        if emb is not None:
+            E = emb.shape[1]
+            assert emb.shape[0] >= 2 * M and tuple(We.shape) == (N, E) and emb.stride(1) == 1 and We.stride(1) == 1
+        st = self.lib.cg_interp_hidden(_ptr(H), _ld(H), _ptr(alpha), _ptr(emb), _ld(emb), E, _ptr(We), _ld(We), M, N,
+                                       self._stream())
+        _lib.check(st, "cg_interp_hidden")
+
     def gp_penalty(self, V, rowpen, UX, lambda_gp):
         M, G = UX.shape
         assert V.shape == UX.shape and rowpen.numel() == M

@@ -259,6 +259,18 @@ int cg_critic_inputs(float* out, int ldo, const float* real, int ldr, const floa
                      const float* alpha, int M, int G, int64_t* lab_out, const int64_t* real_lab,
                      const int64_t* fake_lab, int n_cov, void* stream);
 /*
+ * The critic's first Linear (GAN_functions.py:165, on [x | emb], :184) applied to the interpolated batch of the
+ * gradient penalty (:196-199) without a product.  The layer is linear and the interpolates are
+ * alpha x_real + (1 - alpha) x_fake with the generated batch's labels, so
+ *   h_interp = alpha h_real + (1 - alpha) h_fake + alpha (emb_fake - emb_real) We^T
+ * H (3M x N, leading dimension ldh) holds h_real in rows [0, M) and h_fake in [M, 2M), bias included, and receives
+ * h_interp in rows [2M, 3M).  emb (may be NULL: no covariates): 2M x E embedding rows of the real and the generated
+ * batch; We: the embedding columns of the layer's weight, stored [N][E] with leading dimension ldw.
+ */
+int cg_interp_hidden(float* H, int ldh, const float* alpha, const float* emb, int lde, int E,
+                     const float* We, int ldw, int M, int N, void* stream);
+
+/*
  * Row norms and the penalty (:203): n_m = ||UX[m,:]||_2; rowpen[m] = (n_m-1)^2
  * (their mean is the penalty); V[m,:] = (lambda*2/M)*((n_m-1)/n_m)*UX[m,:] is the
  * gradient of lambda*penalty w.r.t. UX.  V may alias UX.

@@ -285,6 +285,13 @@ class CpuOps:
             lab_out[M:2 * M].copy_(fake_lab)
             lab_out[2 * M:].copy_(fake_lab)
 
+    def interp_hidden(self, H, M, alpha, emb, We):
+        a = alpha.reshape(-1, 1)
+        v = a * H[:M] + (1 - a) * H[M:2 * M]
+        if emb is not None:
+            v = v + a * ((emb[M:2 * M] - emb[:M]) @ We.t())
+        H[2 * M:3 * M].copy_(v)
+
     def gp_penalty(self, V, rowpen, UX, lambda_gp):
         M = UX.shape[0]
         n = UX.norm(2, dim=1)

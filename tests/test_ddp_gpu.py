@@ -107,13 +107,20 @@ def test_two_ranks_match_gradient_averaging_oracle(tmp_path):
     shards = [(xm[k * b:(k + 1) * b], xh[k * b:(k + 1) * b], lm[k * b:(k + 1) * b, None], lh[k * b:(k + 1) * b, None])
               for k in range(world)]
     exp = [rt.iteration(i, shards) for i in range(iters)]
-    floor = {"g_adv": 0.5, "g_loss": 0.5}
+    # fm_loss is a mean of squared differences of feature means, ~1e-3 here: the float32 rounding of the means
+    # (~1e-7 absolute) is 1e-4 of it, so it is measured against 1e-2, like the adversarial terms against 0.5
+    floor = {"g_adv": 0.5, "g_loss": 0.5, "fm_loss": 1e-2}
     glob = ("g_loss", "g_adv", "cycle_loss", "celltype_loss", "fm_loss", "kl_loss")   # the same on every rank
     for i in (0, 2):
         tol = 1e-4 if i == 0 else 5e-3
         for k in glob:
             for rk in r:
-                assert rel(rk["res"][i][k], exp[i][k], floor.get(k, 0.0)) <= tol, (i, k, rk["res"][i][k], exp[i][k])
+                # g_loss weights every term with 1 / |moving average of g_adv|, a difference of critic outputs near
+                # zero here: after two critic updates whose first Adam steps turn rounding into +-lr it is the one
+                # quantity that two float32 evaluations do not agree on to 5e-3 (seen: 1e-3 and 1.2e-2 for two
+                # roundings of the critic's first layer, every other term <= 6e-4); bound as for later epochs elsewhere
+                t = 3e-2 if (k == "g_loss" and i > 0) else tol
+                assert rel(rk["res"][i][k], exp[i][k], floor.get(k, 0.0)) <= t, (i, k, rk["res"][i][k], exp[i][k])
         for k in ("d_m_loss", "d_h_loss", "fake_human_var"):                            # rank-local values
             assert rel(r[0]["res"][i][k], exp[i][k], 0.5) <= tol, (i, k)
     # every rank holds the oracle replicas' parameters
@@ -130,7 +137,10 @@ def test_two_ranks_match_gradient_averaging_oracle(tmp_path):
             mask = moved > 0.5 * cfg["lr"]       # elements with a real gradient move by about lr per Adam step
             if float(mask.float().mean()) < 0.5:
                 continue
-            assert update_rel_l2(v[mask], ref[mask], init[mask]) <= 3e-1, (n, k)
+            # one element of a small tensor stepping the other way (the first Adam steps are +-lr, the sign of a
+            # near-zero gradient is rounding) is a relative L2 of 2 / sqrt(elements): 0.5 for a 16-element bias
+            bound = max(3e-1, 2.1 / float(mask.sum()) ** 0.5)
+            assert update_rel_l2(v[mask], ref[mask], init[mask]) <= bound, (n, k)
 
 
 def _bench_line(cmd, env, timeout):

@@ -103,7 +103,10 @@ def check_updates(nets, tr, eng, tol):
                 continue
             ref = tr.nets[n][k].detach()
             if k.endswith(("running_mean", "running_var")):
-                assert rel(v, ref) <= 5e-3, (n, k)
+                # after five iterations of amplified rounding; two roundings of this very build (the critic's first
+                # layer on the interpolates multiplied out or combined by linearity) give 4.6e-3 and 5.3e-3 on the
+                # worst tensor, with the same errors on the losses
+                assert rel(v, ref) <= 1e-2, (n, k)
                 continue
             g = vmax[(n, k)].sqrt()
             if float(g.max()) == 0.0:      # never received a gradient (the critic's last bias: -1/B*B + 1/B*B)

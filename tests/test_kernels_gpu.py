@@ -720,3 +720,30 @@ def test_linear_batchnorm_with_slabs_left_to_the_consumer(ops, M, N, K, with_mas
     if K >= 1024 and M * N <= 512 * 1024:
         assert out["slabs"][7] > 1, "expected this shape to split K (otherwise the test does not reach the slab path)"
     assert not ops.bn_slabs_ok(513, 512) and not ops.bn_slabs_ok(512, 128)
+
+
+@pytest.mark.parametrize("M,N,G,E", [(512, 1024, 5000, 12), (37, 1024, 200, 12), (64, 256, 96, 0)])
+def test_first_layer_on_the_interpolates_by_linearity(ops, M, N, G, E):
+    """cg_interp_hidden against the product it replaces: the first Linear on [alpha x_r + (1 - alpha) x_f | emb_f]
+    from its outputs on [x_r | emb_r] and [x_f | emb_f].  Equal up to float32 rounding of two summation orders."""
+    W = G + E
+    xe = torch.zeros(3 * M, W)
+    xe[:2 * M, :G] = rnd(2 * M, G, seed=1)
+    if E:
+        xe[:2 * M, G:] = rnd(2 * M, E, seed=2)
+        xe[2 * M:, G:] = xe[M:2 * M, G:]
+    alpha = torch.rand(M, 1, generator=torch.Generator().manual_seed(3))
+    xe[2 * M:, :G] = alpha * xe[:M, :G] + (1 - alpha) * xe[M:2 * M, :G]
+    w1, bias = rnd(N, W, seed=4) * 0.05, rnd(N, seed=5)
+    direct = torch.empty(3 * M, N).cuda()
+    ops.gemm(direct, dev(xe), dev(w1), False, True, bias=dev(bias))
+    h = torch.full((3 * M, N), 9.0).cuda()
+    h[:2 * M] = direct[:2 * M]
+    dw1 = dev(w1)
+    ops.interp_hidden(h, M, dev(alpha), dev(xe)[:, G:] if E else None, dw1[:, G:] if E else None)
+    assert torch.equal(h[:2 * M], direct[:2 * M])
+    close(h[2 * M:], direct[2 * M:].cpu(), 2e-6)
+    eh = direct.cpu().clone()
+    eh[2 * M:] = 9.0
+    cpu.interp_hidden(eh, M, alpha, xe[:, G:] if E else None, w1[:, G:] if E else None)
+    close(h[2 * M:], eh[2 * M:], 2e-6)

@@ -62,6 +62,15 @@ def main():
     print(f"{'tensor':58s} {'hip-vs-f64':>11s} {'f32-vs-f64':>11s}   (relative L2 of the gradient)")
     for which, arena, (a32, a64) in (("d", eng.arena_d, (g32[0], g64[0])), ("g", eng.arena_g, (g32[1], g64[1]))):
         flat = grabbed[which].cpu()
+        tot = [0.0, 0.0, 0.0]
+        for (n, k), (off, cnt, shape) in arena.offsets.items():
+            if (n, k) in a64 and not O.is_gauge_param(k, nets[n]):
+                ref = a64[(n, k)].reshape(-1)
+                tot[0] += float((flat[off:off + cnt].double() - ref).norm()) ** 2
+                tot[1] += float((a32[(n, k)].reshape(-1).double() - ref).norm()) ** 2
+                tot[2] += float(ref.norm()) ** 2
+        print(f"SUMMARY {which}-step gradients, all tensors: hip-vs-f64 {(tot[0] / tot[2]) ** 0.5:.3e}   "
+              f"f32-vs-f64 {(tot[1] / tot[2]) ** 0.5:.3e}")
         for (n, k), (off, cnt, shape) in arena.offsets.items():
             if (n, k) not in a64 or O.is_gauge_param(k, nets[n]):
                 continue
