@@ -28,15 +28,16 @@ class GlossDesc(C.Structure):
 SIGNATURES = {
     "cg_version": ([], I),
     "cg_gemm": ([P, I, P, I, P, I, I, I, I, I, I, I, P, I, P, I, P, I, F, I, P, Z, P], I),
+    "cg_gemm_ex": ([P, I, P, I, P, I, I, I, I, I, I, I, P, I, P, I, P, I, F, I, P, P, Z, P], I),
     "cg_gemm_slabs": ([P, I, P, I, P, I, I, I, I, I, I, I, P, P, Z, P, P], I),
     "cg_bn_fwd_slabs_ok": ([I, I], I),
-    "cg_bn_fwd_slabs": ([P, I, P, I, P, I, P, I, I, P, P, F, P, P, P, P, F, F, P, I, P, I, P], I),
+    "cg_bn_fwd_slabs": ([P, I, P, I, P, I, P, I, I, P, P, F, P, P, P, P, F, F, P, I, P, I, P, I, P], I),
     "cg_interp_hidden": ([P, I, P, P, I, I, P, I, I, I, P], I),
     "cg_bn_workspace_bytes": ([I, I], Z),
     "cg_bn_fwd": ([P, I, P, I, I, I, P, P, F, P, P, P, P, F, F, P, I, P, I, P, I, P, Z, P], I),
     "cg_bn_fwd_static": ([P, I, P, I, I, I, P, P, F, P, P, P, P, F, F, P, I, P, I, P, I, P], I),
     "cg_bn_fwd_seg": ([P, I, P, I, I, I, C.c_uint, I, P, P, F, P, P, P, P, F, F, P, I, P, I, P, I, P, Z, P], I),
-    "cg_bn_bwd_seg": ([P, I, P, I, P, I, P, I, P, I, P, P, P, P, P, I, P, P, F, I, I, I, P, Z, P], I),
+    "cg_bn_bwd_seg": ([P, I, P, I, P, I, P, I, P, I, P, P, P, P, P, I, P, P, F, I, I, I, P, I, P, Z, P], I),
     "cg_tok_blocks": ([I], I),
     "cg_tok_lin_fwd": ([P, P, P, P, P, I, P], I),
     "cg_tok_bn_lin_fwd": ([P, P, P, P, P, P, P, F, P, P, P, P, F, P, P, I, P], I),
@@ -45,22 +46,23 @@ SIGNATURES = {
     "cg_tok_bwd_mid": ([P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, P], I),
     "cg_tok_bwd_in": ([P, P, P, P, P, P, P, P, P, P, P, P, P, I, P], I),
     "cg_tok_wgrad_reduce": ([P, P, P, P, I, P], I),
-    "cg_bn_eval": ([P, I, P, I, I, I, P, P, P, P, F, F, P], I),
-    "cg_bn_bwd": ([P, I, P, I, P, I, P, I, P, I, P, P, P, P, P, I, P, P, F, I, I, P, Z, P], I),
+    "cg_bn_eval": ([P, I, P, I, I, I, P, P, P, P, F, F, P, I, P], I),
+    "cg_bn_bwd": ([P, I, P, I, P, I, P, I, P, I, P, P, P, P, P, I, P, P, F, I, I, P, I, P, Z, P], I),
     "cg_bn_bwd_bwd": ([P, I, P, I, P, I, P, I, P, I, P, I, P, P, P, P, P, I, I, P, Z, P], I),
     "cg_axpby": ([P, I, F, P, I, F, P, I, I, I, P], I),
     "cg_mul": ([P, I, P, I, P, I, I, I, P], I),
     "cg_fill_coef": ([P, I, I, I, P, I, F, P], I),
     "cg_to_bf16": ([P, I, P, I, I, I, P], I),
-    "cg_embed_gather": ([P, I, P, I, P, I, I, I, P], I),
+    "cg_embed_gather": ([P, I, P, I, P, I, I, I, P, P], I),
+    "cg_copy_bf16": ([P, P, I, P, I, I, I, P], I),
     "cg_embed_scatter": ([P, I, P, I, P, I, I, I, I, P], I),
     "cg_reparam_fwd": ([P, I, P, I, P, I, I, P], I),
     "cg_reparam_bwd": ([P, I, P, I, P, I, P, P, I, F, I, I, P], I),
     "cg_libsize_fwd": ([P, I, P, I, P, F, I, I, P], I),
     "cg_libsize_bwd": ([P, I, P, I, P, I, P, F, I, I, P], I),
     "cg_gp_interp": ([P, I, P, I, P, I, P, I, I, P], I),
-    "cg_critic_inputs": ([P, I, P, I, P, I, P, I, I, P, P, P, I, P], I),
-    "cg_gp_penalty": ([P, I, P, P, I, F, I, I, P], I),
+    "cg_critic_inputs": ([P, I, P, I, P, I, P, I, I, P, P, P, I, P, P], I),
+    "cg_gp_penalty": ([P, I, P, P, I, F, I, I, P, P], I),
     "cg_reduce_sum": ([P, P, P, I, I, I, P], I),
     "cg_reduce_l1": ([P, P, P, I, P, I, I, I, P], I),
     "cg_reduce_poisson": ([P, P, P, I, P, I, I, I, P], I),

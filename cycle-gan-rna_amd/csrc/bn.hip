@@ -163,14 +163,17 @@ __global__ void __launch_bounds__(256) bn_fwd_apply(const double* ws, float* Y, 
 
 __global__ void __launch_bounds__(256) bn_eval_kernel(float* Y, int ldy, const float* X, int ldx, int M, int N,
                                                       const float* gamma, const float* beta, const float* rmean,
-                                                      const float* rvar, float eps, float slope) {
+                                                      const float* rvar, float eps, float slope, u16* ybf,
+                                                      int ldybf) {
   const int c = threadIdx.x & (CW - 1), r0 = threadIdx.x / CW;
   const int col = blockIdx.x * CW + c;
   if (col >= N) return;
   const float mean = rmean[col], invstd = 1.f / sqrtf(rvar[col] + eps), ga = gamma[col], be = beta[col];
   for (int m = blockIdx.y * RL + r0; m < M; m += RL * gridDim.y) {
     const float h = (X[(size_t)m * ldx + col] - mean) * invstd * ga + be;
-    Y[(size_t)m * ldy + col] = h > 0.f ? h : h * slope;
+    const float y = h > 0.f ? h : h * slope;
+    Y[(size_t)m * ldy + col] = y;
+    if (ybf) ybf[(size_t)m * ldybf + col] = f2bf(y);
   }
 }
 
@@ -198,7 +201,7 @@ __global__ void __launch_bounds__(256) bn_bwd_apply(const double* ws, float* dX,
                                                     int ldpm, const float* mean, const float* invstd,
                                                     const float* gamma, float* dgamma, float* dbeta, int accumulate,
                                                     float* gbar_out, float* gxbar_out, float slope, int M, int N,
-                                                    int rows) {
+                                                    int rows, u16* dxbf, int lddxbf) {
   __shared__ double lds[2 * RL * CW];
   BN_COMMON
   const size_t seg_ws = (size_t)2 * gridDim.y * N;
@@ -228,7 +231,9 @@ __global__ void __launch_bounds__(256) bn_bwd_apply(const double* ws, float* dX,
   for (int m = m0 + r0; m < m1; m += RL) {
     const float g = dY[(size_t)m * lddy + col] * pm_of(Y, ldy, PM, ldpm, slope, m, col);
     const float xh = (X[(size_t)m * ldx + col] - mu) * is;
-    dX[(size_t)m * lddx + col] = k * (g - gbar - xh * gxbar);
+    const float d = k * (g - gbar - xh * gxbar);
+    dX[(size_t)m * lddx + col] = d;
+    if (dxbf) dxbf[(size_t)m * lddxbf + col] = f2bf(d);
   }
 }
 
@@ -327,7 +332,8 @@ __global__ void __launch_bounds__(256) bn_bwd_fused(float* dX, int lddx, const f
                                                     int ldx, const float* Y, int ldy, const float* PM, int ldpm,
                                                     const float* mean, const float* invstd, const float* gamma,
                                                     float* dgamma, float* dbeta, int accumulate, float* gbar_out,
-                                                    float* gxbar_out, float slope, int M, int N) {
+                                                    float* gxbar_out, float slope, int M, int N, u16* dxbf,
+                                                    int lddxbf) {
   constexpr int LANES = 256 / CWF;
   __shared__ double lds[2 * 256];
   const int c = threadIdx.x % CWF, r0 = threadIdx.x / CWF, col = blockIdx.x * CWF + c;
@@ -372,7 +378,9 @@ __global__ void __launch_bounds__(256) bn_bwd_fused(float* dX, int lddx, const f
   for (int i = 0; i < NR; ++i) {
     const int m = r0 + i * LANES;
     if (m >= M) break;
-    dX[(size_t)m * lddx + col] = k * (g[i] - gbar - xh[i] * gxbar);
+    const float d = k * (g[i] - gbar - xh[i] * gxbar);
+    dX[(size_t)m * lddx + col] = d;
+    if (dxbf) dxbf[(size_t)m * lddxbf + col] = f2bf(d);
   }
 }
 
@@ -477,14 +485,14 @@ extern "C" int cg_bn_fwd_slabs(float* Y, int ldy, float* X, int ldx, const float
                                const float* x_bias, int M, int N, const float* gamma, const float* beta, float eps,
                                float* mean_out, float* invstd_out, float* running_mean, float* running_var,
                                float momentum, float slope, const float* mask, int ldmask, float* pm_out, int ldpm,
-                               void* stream) {
+                               void* ybf16, int ldybf16, void* stream) {
   if (!Y || !X || !slabs || !gamma || !beta || !mean_out || !invstd_out || M <= 0 || N <= 0 || n_slabs < 1)
     return CG_ERR_BAD_ARG;
-  if (ldy < N || ldx < N || (mask && ldmask < N) || (pm_out && ldpm < N)) return CG_ERR_BAD_ARG;
+  if (ldy < N || ldx < N || (mask && ldmask < N) || (pm_out && ldpm < N) || (ybf16 && ldybf16 < N)) return CG_ERR_BAD_ARG;
   if (!cg_bn_fwd_slabs_ok(M, N)) return CG_ERR_UNSUPPORTED;      // only the one-launch form reads slabs
   hipLaunchKernelGGL((bn_fwd_fused<16, 32, true>), dim3((N + 15) / 16), dim3(256), 0, (hipStream_t)stream, Y, ldy, X,
                      ldx, M, N, gamma, beta, eps, mean_out, invstd_out, running_mean, running_var, momentum, slope, mask,
-                     ldmask, pm_out, ldpm, (u16*)nullptr, 0, slabs, n_slabs, x_bias);
+                     ldmask, pm_out, ldpm, (u16*)ybf16, ldybf16, slabs, n_slabs, x_bias);
   return cg_launch_status();
 }
 
@@ -525,38 +533,38 @@ extern "C" int cg_bn_fwd_static(float* Y, int ldy, const float* X, int ldx, int 
 
 extern "C" int cg_bn_eval(float* Y, int ldy, const float* X, int ldx, int M, int N, const float* gamma,
                           const float* beta, const float* running_mean, const float* running_var, float eps,
-                          float slope, void* stream) {
+                          float slope, void* ybf16, int ldybf16, void* stream) {
   if (!Y || !X || !gamma || !beta || !running_mean || !running_var || M <= 0 || N <= 0) return CG_ERR_BAD_ARG;
-  if (ldy < N || ldx < N) return CG_ERR_BAD_ARG;
+  if (ldy < N || ldx < N || (ybf16 && ldybf16 < N)) return CG_ERR_BAD_ARG;
   int gy = (M + RL * 16 - 1) / (RL * 16);
   if (gy > 64) gy = 64;
   hipLaunchKernelGGL(bn_eval_kernel, dim3((N + CW - 1) / CW, gy), dim3(256), 0, (hipStream_t)stream, Y, ldy, X, ldx,
-                     M, N, gamma, beta, running_mean, running_var, eps, slope);
+                     M, N, gamma, beta, running_mean, running_var, eps, slope, (u16*)ybf16, ldybf16);
   return cg_launch_status();
 }
 
 extern "C" int cg_bn_bwd(float* dX, int lddx, const float* dY, int lddy, const float* X, int ldx, const float* Y,
                          int ldy, const float* PM, int ldpm, const float* mean, const float* invstd,
                          const float* gamma, float* dgamma, float* dbeta, int accumulate, float* gbar_out,
-                         float* gxbar_out, float slope, int M, int N, void* workspace, size_t workspace_bytes,
-                         void* stream) {
+                         float* gxbar_out, float slope, int M, int N, void* dxbf16, int lddxbf16, void* workspace,
+                         size_t workspace_bytes, void* stream) {
   return cg_bn_bwd_seg(dX, lddx, dY, lddy, X, ldx, Y, ldy, PM, ldpm, mean, invstd, gamma, dgamma, dbeta, accumulate,
-                       gbar_out, gxbar_out, slope, M, 1, N, workspace, workspace_bytes, stream);
+                       gbar_out, gxbar_out, slope, M, 1, N, dxbf16, lddxbf16, workspace, workspace_bytes, stream);
 }
 
 extern "C" int cg_bn_bwd_seg(float* dX, int lddx, const float* dY, int lddy, const float* X, int ldx, const float* Y,
                              int ldy, const float* PM, int ldpm, const float* mean, const float* invstd,
                              const float* gamma, float* dgamma, float* dbeta, int accumulate, float* gbar_out,
-                             float* gxbar_out, float slope, int seg_rows, int nseg, int N, void* workspace,
-                             size_t workspace_bytes, void* stream) {
+                             float* gxbar_out, float slope, int seg_rows, int nseg, int N, void* dxbf16,
+                             int lddxbf16, void* workspace, size_t workspace_bytes, void* stream) {
   const int M = seg_rows;
   if (!dX || !dY || !X || !mean || !invstd || !gamma || M <= 0 || N <= 0 || nseg < 1 || nseg > 8) return CG_ERR_BAD_ARG;
-  if (lddx < N || lddy < N || ldx < N || (Y && ldy < N) || (PM && ldpm < N)) return CG_ERR_BAD_ARG;
+  if (lddx < N || lddy < N || ldx < N || (Y && ldy < N) || (PM && ldpm < N) || (dxbf16 && lddxbf16 < N)) return CG_ERR_BAD_ARG;
   if (!workspace || workspace_bytes < nseg * cg_bn_workspace_bytes(M, N)) return CG_ERR_WORKSPACE;
   if (nseg == 1 && M <= 512 && N >= 256) {      // one launch (see bn_bwd_fused)
     hipLaunchKernelGGL((bn_bwd_fused<16, 32>), dim3((N + 15) / 16), dim3(256), 0, (hipStream_t)stream, dX, lddx, dY,
                        lddy, X, ldx, Y, ldy, PM, ldpm, mean, invstd, gamma, dgamma, dbeta, accumulate, gbar_out,
-                       gxbar_out, slope, M, N);
+                       gxbar_out, slope, M, N, (u16*)dxbf16, lddxbf16);
     return cg_launch_status();
   }
   const Geo g = geo(M, N);
@@ -565,7 +573,7 @@ extern "C" int cg_bn_bwd_seg(float* dX, int lddx, const float* dY, int lddy, con
                      ldy, PM, ldpm, mean, invstd, slope, M, N, g.rows);
   hipLaunchKernelGGL(bn_bwd_apply, grid, dim3(256), 0, (hipStream_t)stream, (const double*)workspace, dX, lddx, dY,
                      lddy, X, ldx, Y, ldy, PM, ldpm, mean, invstd, gamma, dgamma, dbeta, accumulate, gbar_out,
-                     gxbar_out, slope, M, N, g.rows);
+                     gxbar_out, slope, M, N, g.rows, (u16*)dxbf16, lddxbf16);
   return cg_launch_status();
 }
 

@@ -46,14 +46,25 @@ __global__ void to_bf16_kernel(u16* out, int ldo, const float* x, int ldx, int M
   CG_2D_LOOP(M, N) out[(size_t)m * ldo + col] = f2bf(x[(size_t)m * ldx + col]);
 }
 
+// out <- x and out16 <- bf16(x), both with leading dimension ldo
+__global__ void copy_bf16_kernel(float* out, u16* out16, int ldo, const float* x, int ldx, int M, int N) {
+  CG_2D_LOOP(M, N) {
+    const float v = x[(size_t)m * ldx + col];
+    out[(size_t)m * ldo + col] = v;
+    out16[(size_t)m * ldo + col] = f2bf(v);
+  }
+}
+
 __global__ void embed_gather_kernel(float* out, int ldo, const float* table, int E, const int64_t* labels,
-                                    int lstride, int M, int n_types) {
+                                    int lstride, int M, int n_types, u16* out16) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= M * E) return;
   const int m = i / E, e = i % E;
   int64_t t = labels[(size_t)m * lstride];
   t = t < 0 ? 0 : (t >= n_types ? n_types - 1 : t);
-  out[(size_t)m * ldo + e] = table[t * E + e];
+  const float v = table[t * E + e];
+  out[(size_t)m * ldo + e] = v;
+  if (out16) out16[(size_t)m * ldo + e] = f2bf(v);
 }
 
 // One block per table row (cell type): 64 row lanes x 16 column lanes walk the batch, then the row lanes are
@@ -156,12 +167,18 @@ __global__ void gp_interp_kernel(float* out, int ldo, const float* real, int ldr
 // interpolates; and their labels (n_cov int64 per row): real's, fake's, fake's.
 __global__ void critic_inputs_kernel(float* out, int ldo, const float* real, int ldr, const float* fake, int ldf,
                                      const float* alpha, int M, int G, int64_t* lab_out, const int64_t* real_lab,
-                                     const int64_t* fake_lab, int n_cov) {
+                                     const int64_t* fake_lab, int n_cov, u16* out16) {
   CG_2D_LOOP(M, G) {
     const float a = alpha[m], r = real[(size_t)m * ldr + col], f = fake[(size_t)m * ldf + col];
+    const float x = a * r + (1.f - a) * f;
     out[(size_t)m * ldo + col] = r;
     out[(size_t)(M + m) * ldo + col] = f;
-    out[(size_t)(2 * M + m) * ldo + col] = a * r + (1.f - a) * f;
+    out[(size_t)(2 * M + m) * ldo + col] = x;
+    if (out16) {
+      out16[(size_t)m * ldo + col] = f2bf(r);
+      out16[(size_t)(M + m) * ldo + col] = f2bf(f);
+      out16[(size_t)(2 * M + m) * ldo + col] = f2bf(x);
+    }
   }
   if (lab_out && blockIdx.x == 0 && blockIdx.y == 0) {
     const int t = threadIdx.y * blockDim.x + threadIdx.x, nt = blockDim.x * blockDim.y;
@@ -193,7 +210,7 @@ __global__ void interp_hidden_kernel(float* H, int ldh, const float* alpha, cons
 }
 
 __global__ void __launch_bounds__(256) gp_penalty_kernel(float* V, int ldv, float* rowpen, const float* UX, int ldu,
-                                                         float lam2_over_m, int G) {
+                                                         float lam2_over_m, int G, u16* V16) {
   __shared__ float lds[17];
   const int m = blockIdx.x;
   float s = 0.f;
@@ -206,7 +223,11 @@ __global__ void __launch_bounds__(256) gp_penalty_kernel(float* V, int ldv, floa
   if (threadIdx.x == 0) rowpen[m] = (n - 1.f) * (n - 1.f);
   // d/du of (n-1)^2 is 2 (n-1) u / n; torch's norm backward yields 0 at n = 0
   const float k = n > 0.f ? lam2_over_m * (n - 1.f) / n : 0.f;
-  for (int c = threadIdx.x; c < G; c += 256) V[(size_t)m * ldv + c] = k * UX[(size_t)m * ldu + c];
+  for (int c = threadIdx.x; c < G; c += 256) {
+    const float v = k * UX[(size_t)m * ldu + c];
+    V[(size_t)m * ldv + c] = v;
+    if (V16) V16[(size_t)m * ldv + c] = f2bf(v);
+  }
 }
 
 // ---- reductions ----------------------------------------------------------- //
@@ -483,12 +504,20 @@ extern "C" int cg_to_bf16(void* out, int ldo, const float* x, int ldx, int M, in
   return cg_launch_status();
 }
 
+extern "C" int cg_copy_bf16(float* out, void* out_bf16, int ldo, const float* x, int ldx, int M, int N, void* stream) {
+  if (!out || !out_bf16 || !x || M < 0 || N < 0 || ldo < N || ldx < N) return CG_ERR_BAD_ARG;
+  if (M == 0 || N == 0) return CG_OK;
+  Grid2 g = grid2(M, N);
+  hipLaunchKernelGGL(copy_bf16_kernel, g.grid, g.block, 0, ST, out, (u16*)out_bf16, ldo, x, ldx, M, N);
+  return cg_launch_status();
+}
+
 extern "C" int cg_embed_gather(float* out, int ldo, const float* table, int E, const int64_t* labels, int lstride,
-                               int M, int n_types, void* stream) {
+                               int M, int n_types, void* out_bf16, void* stream) {
   if (!out || !table || !labels || E <= 0 || M < 0 || ldo < E || lstride < 1 || n_types <= 0) return CG_ERR_BAD_ARG;
   if (M == 0) return CG_OK;
   hipLaunchKernelGGL(embed_gather_kernel, dim3((M * E + 255) / 256), dim3(256), 0, ST, out, ldo, table, E, labels,
-                     lstride, M, n_types);
+                     lstride, M, n_types, (u16*)out_bf16);
   return cg_launch_status();
 }
 
@@ -544,12 +573,12 @@ extern "C" int cg_gp_interp(float* out, int ldo, const float* real, int ldr, con
 
 extern "C" int cg_critic_inputs(float* out, int ldo, const float* real, int ldr, const float* fake, int ldf,
                                 const float* alpha, int M, int G, int64_t* lab_out, const int64_t* real_lab,
-                                const int64_t* fake_lab, int n_cov, void* stream) {
+                                const int64_t* fake_lab, int n_cov, void* out_bf16, void* stream) {
   if (!out || !real || !fake || !alpha || M <= 0 || G <= 0 || ldo < G || ldr < G || ldf < G) return CG_ERR_BAD_ARG;
   if (lab_out && (!real_lab || !fake_lab || n_cov <= 0)) return CG_ERR_BAD_ARG;
   Grid2 g = grid2(M, G);
   hipLaunchKernelGGL(critic_inputs_kernel, g.grid, g.block, 0, ST, out, ldo, real, ldr, fake, ldf, alpha, M, G, lab_out,
-                     real_lab, fake_lab, n_cov);
+                     real_lab, fake_lab, n_cov, (u16*)out_bf16);
   return cg_launch_status();
 }
 
@@ -563,10 +592,10 @@ extern "C" int cg_interp_hidden(float* H, int ldh, const float* alpha, const flo
 }
 
 extern "C" int cg_gp_penalty(float* V, int ldv, float* rowpen, const float* UX, int ldu, float lambda_gp, int M, int G,
-                             void* stream) {
+                             void* v_bf16, void* stream) {
   if (!V || !rowpen || !UX || M <= 0 || G <= 0 || ldv < G || ldu < G) return CG_ERR_BAD_ARG;
   hipLaunchKernelGGL(gp_penalty_kernel, dim3(M), dim3(256), 0, ST, V, ldv, rowpen, UX, ldu, lambda_gp * 2.f / (float)M,
-                     G);
+                     G, (u16*)v_bf16);
   return cg_launch_status();
 }
 

@@ -54,6 +54,7 @@ struct GemmArgs {
   int kt_per_split;   // K slabs handled by one blockIdx.y (split-K); all of them when gridDim.y == 1
   float* ws;          // split-K: partial results [gridDim.y][M][N]
   unsigned a_bytes, b_bytes;   // footprints of A and B in memory (hardware range check of the buffer loads)
+  u16* C16;           // optional bf16 image of C (same leading dimension): every value stored to C is also stored here
 };
 
 #ifndef CG_BK
@@ -145,17 +146,19 @@ struct Stager {
 // One output element through the epilogue (bias already added by the caller where it applies).
 __device__ __forceinline__ void epilogue_store(const GemmArgs& g, int row, int col, float h) {
   float* cp = g.C + (size_t)row * g.ldc + col;
+  float out;
   if (g.epi == CG_EPI_NONE) {
-    if (g.accumulate) h += *cp;
-    *cp = h;
+    out = g.accumulate ? h + *cp : h;
   } else if (g.epi == CG_EPI_LEAKY) {
     float pm = h > 0.f ? 1.f : g.slope;
     if (g.E) pm *= g.E[(size_t)row * g.lde + col];
-    *cp = h * pm;
+    out = h * pm;
     if (g.aux) g.aux[(size_t)row * g.ldaux + col] = pm;
   } else {
-    *cp = h * g.E[(size_t)row * g.lde + col];
+    out = h * g.E[(size_t)row * g.lde + col];
   }
+  *cp = out;
+  if (g.C16) g.C16[(size_t)row * g.ldc + col] = f2bf(out);
 }
 
 // XCD-aware tile index: workgroups are dealt round-robin over the 8 XCDs; give each XCD a contiguous run of
@@ -876,6 +879,11 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(GemmArgs g, int spli
     }
     if (VEC4) *reinterpret_cast<f32x4*>(cp) = f32x4{out[0], out[W > 1 ? 1 : 0], out[W > 2 ? 2 : 0], out[W > 3 ? 3 : 0]};
     else cp[0] = out[0];
+    if (g.C16) {
+      u16* hp = g.C16 + (size_t)m * g.ldc + n;
+      if (VEC4) *reinterpret_cast<uint2*>(hp) = pack4(out[0], out[W > 1 ? 1 : 0], out[W > 2 ? 2 : 0], out[W > 3 ? 3 : 0]);
+      else hp[0] = f2bf(out[0]);
+    }
   }
 }
 
@@ -921,6 +929,75 @@ __global__ void __launch_bounds__(256) gemm_small_n_kernel(GemmArgs g, Strides s
   }
 }
 
+// 3 <= N <= 16, op(A) with k contiguous (the input gradient of the critic's embedding columns, dh0 * W1[:, G:]: 12
+// columns, K = 1024): a 64-wide MFMA tile would be mostly padding and needs split-K plus a reduce launch to cover a
+// few CUs.  Here a lane owns one output element - a wave covers 4 rows x 16 columns, a workgroup 16 rows - and walks
+// the whole of K itself, so no sum crosses lanes (k-ordered chain, nothing to reduce).  Both operands go through LDS
+// in chunks of 256 k: op(B) transposed to [column][k], A as [row][k], row stride 260 floats, so the 16 columns (and
+// the 4 rows) of a ds_read_b128 start 4 banks apart and the 16 lanes of a row read one broadcast address.  The kernel
+// is bound by load latency, not by bytes: a chunk's global loads are all issued at once, unconditionally (index
+// clamped, value discarded), into registers while the previous chunk is multiplied out of LDS.
+// VEC: A rows 16-byte aligned and K a multiple of 4.
+constexpr int SN_KC = 256, SN_KS = SN_KC + 4, SN_ROWS = 16;
+template <bool VEC>
+__global__ void __launch_bounds__(256) gemm_small_n16_kernel(GemmArgs g, Strides st) {
+  __shared__ __align__(16) float as[SN_ROWS * SN_KS];
+  __shared__ __align__(16) float bs[16 * SN_KS];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int n = lane & 15, rl = wave * 4 + (lane >> 4), row = blockIdx.x * SN_ROWS + rl;
+  // staging roles: B - column tn, k = tk + 16 j; A - row tk, k = 4 (tn + 16 j) .. + 3 (VEC) or k = tn + 16 j
+  const int tn = t & 15, tk = t >> 4, tnc = min(tn, g.N - 1);
+  const float* arow = g.A + (size_t)min(blockIdx.x * SN_ROWS + tk, g.M - 1) * st.am;
+  float vb[16], va[16];
+  f32x4 va4[4];
+  auto fetch = [&](int kc) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) vb[j] = g.B[(size_t)min(kc + tk + 16 * j, g.K - 1) * st.bk + (size_t)tnc * st.bn];
+    if (VEC) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) va4[j] = *reinterpret_cast<const f32x4*>(arow + min(kc + 4 * (tn + 16 * j), g.K - 4));
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) va[j] = arow[min(kc + tn + 16 * j, g.K - 1)];
+    }
+  };
+  auto stash = [&](int kc) {      // what lies past the end of K goes to LDS as zeros
+    const int kn = g.K - kc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) bs[tn * SN_KS + tk + 16 * j] = (tn < g.N && tk + 16 * j < kn) ? vb[j] : 0.f;
+    if (VEC) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = 4 * (tn + 16 * j);
+        *reinterpret_cast<f32x4*>(as + tk * SN_KS + k) = k < kn ? va4[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) as[tk * SN_KS + tn + 16 * j] = tn + 16 * j < kn ? va[j] : 0.f;
+    }
+  };
+  float acc = 0.f;
+  fetch(0);
+  for (int kc = 0; kc < g.K; kc += SN_KC) {
+    __syncthreads();      // every wave has finished reading the previous chunk
+    stash(kc);
+    __syncthreads();
+    fetch(kc + SN_KC);    // the next chunk (clamped re-reads once K is exhausted), in flight during the products below
+    const float* al = as + rl * SN_KS;
+    const float* bl = bs + n * SN_KS;
+#pragma unroll 8
+    for (int q = 0; q < SN_KC / 4; ++q) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(al + 4 * q);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(bl + 4 * q);
+      acc = fmaf(a[0], b[0], acc);
+      acc = fmaf(a[1], b[1], acc);
+      acc = fmaf(a[2], b[2], acc);
+      acc = fmaf(a[3], b[3], acc);
+    }
+  }
+  if (row < g.M && n < g.N) epilogue_store(g, row, n, acc + (g.bias ? g.bias[n] : 0.f));
+}
+
 // M <= 2 with A stored [K][M] and B stored [K][N] (a weight gradient of the critic's one-column head: dval^T a3): a
 // workgroup owns 32 columns, its 32 row lanes stride over k, partial sums are added in lane order.
 __global__ void __launch_bounds__(1024) gemm_small_m_kernel(GemmArgs g) {
@@ -963,13 +1040,20 @@ bool launch_small(const GemmArgs& g, int transA, int transB, hipStream_t st) {
     hipLaunchKernelGGL(gemm_small_n_kernel, dim3((g.M + 3) / 4), dim3(256), 0, st, g, s);
     return true;
   }
+  if (g.N <= 16 && !transA) {
+    const bool v4 = (uintptr_t)g.A % 16 == 0 && g.lda % 4 == 0 && g.K % 4 == 0;
+    if (v4) hipLaunchKernelGGL(gemm_small_n16_kernel<true>, dim3((g.M + SN_ROWS - 1) / SN_ROWS), dim3(256), 0, st, g, s);
+    else hipLaunchKernelGGL(gemm_small_n16_kernel<false>, dim3((g.M + SN_ROWS - 1) / SN_ROWS), dim3(256), 0, st, g, s);
+    return true;
+  }
   return false;
 }
 
 void launch_splitk_reduce(const GemmArgs& g, int splits, hipStream_t st) {
   const size_t total = (size_t)g.M * g.N;
   auto al = [](const void* p, int ld) { return p == nullptr || (((uintptr_t)p % 16 == 0) && ld % 4 == 0); };
-  const bool v4 = g.N % 4 == 0 && al(g.C, g.ldc) && al(g.E, g.lde) && al(g.aux, g.ldaux) && al(g.ws, 4);
+  const bool v4 = g.N % 4 == 0 && al(g.C, g.ldc) && al(g.E, g.lde) && al(g.aux, g.ldaux) && al(g.ws, 4) &&
+                  (uintptr_t)g.C16 % 8 == 0;
   int blocks = (int)((total / (v4 ? 4 : 1) + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   if (v4) hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(blocks), dim3(256), 0, st, g, splits);
@@ -1052,8 +1136,10 @@ int launch_f32_dma(const GemmArgs& g, int transA, int transB, hipStream_t st, in
 int gemm_dispatch(float* C, int ldc, const void* A, int lda, const void* B, int ldb,
                   int M, int N, int K, int transA, int transB, int dtype,
                   const float* bias, int epi, const float* E, int lde, float* aux, int ldaux,
-                  float slope, int accumulate, void* workspace, size_t workspace_bytes, void* stream, int* keep) {
+                  float slope, int accumulate, void* workspace, size_t workspace_bytes, void* stream, int* keep,
+                  void* c_bf16 = nullptr) {
   if (!C || !A || !B || M < 0 || N < 0 || K < 0) return CG_ERR_BAD_ARG;
+  if (c_bf16 && (keep || (uintptr_t)c_bf16 % 2)) return CG_ERR_BAD_ARG;
   if (M == 0 || N == 0) return CG_OK;
   if (K == 0) return CG_ERR_BAD_ARG;      // an empty sum has no tile to launch; callers never need it
   if (epi < CG_EPI_NONE || epi > CG_EPI_MUL) return CG_ERR_BAD_ARG;
@@ -1075,8 +1161,8 @@ int gemm_dispatch(float* C, int ldc, const void* A, int lda, const void* B, int 
   if (bh && (((uintptr_t)B % 8) || ldb % 4 || b_cols % 2)) return CG_ERR_UNSUPPORTED;
   if (a_bytes >= OOB_OFF || b_bytes >= OOB_OFF) return CG_ERR_UNSUPPORTED;   // 32-bit buffer offsets
   GemmArgs g{(const float*)A, (const float*)B, C, bias, E, aux, M, N, K, lda, ldb, ldc, lde, ldaux,
-             epi, accumulate, slope, 0, 1 << 30, (float*)workspace, (unsigned)a_bytes, (unsigned)b_bytes};
-  const bool tiny = K <= 16 || N <= 2 || (M <= 2 && transA && !transB);
+             epi, accumulate, slope, 0, 1 << 30, (float*)workspace, (unsigned)a_bytes, (unsigned)b_bytes, (u16*)c_bf16};
+  const bool tiny = K <= 16 || N <= 2 || (M <= 2 && transA && !transB) || (N <= 16 && !transA);
   if (tiny && (ah || bh)) return CG_ERR_UNSUPPORTED;      // the plain-FMA kernels read float32
   if (tiny && launch_small(g, transA, transB, st)) {
     if (keep) *keep = 1;
@@ -1181,6 +1267,14 @@ extern "C" int cg_gemm(float* C, int ldc, const void* A, int lda, const void* B,
                        float slope, int accumulate, void* workspace, size_t workspace_bytes, void* stream) {
   return gemm_dispatch(C, ldc, A, lda, B, ldb, M, N, K, transA, transB, dtype, bias, epi, E, lde, aux, ldaux, slope,
                        accumulate, workspace, workspace_bytes, stream, nullptr);
+}
+
+extern "C" int cg_gemm_ex(float* C, int ldc, const void* A, int lda, const void* B, int ldb,
+                          int M, int N, int K, int transA, int transB, int dtype,
+                          const float* bias, int epi, const float* E, int lde, float* aux, int ldaux,
+                          float slope, int accumulate, void* c_bf16, void* workspace, size_t workspace_bytes, void* stream) {
+  return gemm_dispatch(C, ldc, A, lda, B, ldb, M, N, K, transA, transB, dtype, bias, epi, E, lde, aux, ldaux, slope,
+                       accumulate, workspace, workspace_bytes, stream, nullptr, c_bf16);
 }
 
 extern "C" int cg_gemm_slabs(float* C, int ldc, const void* A, int lda, const void* B, int ldb,

@@ -210,9 +210,12 @@ class GenPass:
         # BatchNorm kernels
         self.fused_tok = self.D == 16
         Z, B, H, L, D = ops.zeros, max_b, self.hidden, self.L, self.D
+        # workspaces that only gemm / bn_fwd* / bn_eval / bn_bwd write and that products read next: in bf16 mode the
+        # HIP backend keeps a bf16 image of them (ops.shadowed), which those products read instead
+        Zs = getattr(ops, "shadowed", Z)
         T = B * SEQ_LEN
         self.enc_h0 = [Z(B, h) for h in H]
-        self.enc_a = [Z(B, h) for h in H]
+        self.enc_a = [Zs(B, h) for h in H]
         self.enc_stats = [(Z(h), Z(h)) for h in H]
         self.ml = Z(B, 2 * L)
         self.z = [Z(B, L) for _ in range(self.nb + 1)]
@@ -229,15 +232,17 @@ class GenPass:
             self.tok_wpart = [Z(nblk * 256), Z(nblk * 256)]                           # per-workgroup 16x16 weight grads
         self.dec_in = Z(B, L + self.E)
         self.dec_h0 = [Z(B, h) for h in H]
-        self.dec_a = [Z(B, h) for h in H]
+        self.dec_a = [Zs(B, h) for h in H]
         self.dec_stats = [(Z(h), Z(h)) for h in H]
-        self.out_raw = Z(B, out_dim)
+        # without library-size normalisation the last product's result is the generated batch itself, which the
+        # other generator's first layer (cycle pass) and its weight gradient read
+        self.out_raw = Z(B, out_dim) if self.counts else Zs(B, out_dim)
         self.out = Z(B, out_dim) if self.counts else self.out_raw
         self.rowsum = Z(B)
         # backward scratch
         self.d_out_raw = Z(B, out_dim) if self.counts else None
         self.d_act = [Z(B, h) for h in H]
-        self.d_h0 = [Z(B, h) for h in H]
+        self.d_h0 = [Zs(B, h) for h in H]
         self.d_dec_in = Z(B, L + self.E)
         self.dz = [Z(B, L), Z(B, L)]
         self.d16 = [Z(T, D), Z(T, D)]
@@ -247,6 +252,12 @@ class GenPass:
         self.labels = None
         self.x = None
         self.b = 0
+        # bf16 mode: a bf16 image of the input batch for the first layer's product and its weight gradient (unless the
+        # batch already has one: the other generator's output in a cycle pass)
+        self.x16 = None
+        if getattr(ops, "precision", "fp32") == "bf16" and hasattr(ops, "image_of"):
+            self.x16 = ops.zeros(B * _pad4(in_dim), dtype=torch.bfloat16)
+        self.x_img = None
         # [mu; log_var] as one matrix (see _arena_order)
         ar, hl = net.arena, H[-1]
         self.W_ml = ar.flat(ar.p, (net.name, "mu.weight"), 2 * L * hl).view(2 * L, hl)
@@ -265,13 +276,14 @@ class GenPass:
         P, Bf = self.net.P, self.net.B
         return (P[prefix + ".weight"], P[prefix + ".bias"], Bf[prefix + ".running_mean"], Bf[prefix + ".running_var"])
 
-    def _linear_bn_relu(self, out_a, out_h0, stats, a, lin, bn, train):
+    def _linear_bn_relu(self, out_a, out_h0, stats, a, lin, bn, train, a16=None):
         ops, P = self.ops, self.net.P
         gamma, beta, rm, rv = self._bn(bn)
         # when the product splits K, the BatchNorm adds the partial sums itself while it loads its input: one launch
         # and one pass over the pre-activation less
         slabs = train and ops.bn_slabs_ok(*out_h0.shape)
-        n = ops.gemm(out_h0, a, P[lin + ".weight"], False, True, bias=P[lin + ".bias"], keep_slabs=slabs)
+        kw = {} if a16 is None else dict(a16=a16)
+        n = ops.gemm(out_h0, a, P[lin + ".weight"], False, True, bias=P[lin + ".bias"], keep_slabs=slabs, **kw)
         if slabs and n > 1:
             ops.bn_fwd_slabs(out_a, out_h0, n, P[lin + ".bias"], gamma, beta, stats[0], stats[1], rm, rv, 0.0)
             self.net.nbt[bn + ".num_batches_tracked"] += 1
@@ -287,9 +299,13 @@ class GenPass:
         self.b, self.x, self.labels, self.train = b, x, labels, train
         nh = len(self.hidden)
         a = x
+        self.x_img = None
+        if self.x16 is not None and x.dim() == 2 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.stride(0) <= _pad4(self.in_dim):
+            self.x_img = ops.image_of(x, self.x16)
         for li in range(nh):
             self._linear_bn_relu(self.enc_a[li][:b], self.enc_h0[li][:b], self.enc_stats[li], a,
-                                 f"encoder.{3 * li}", f"encoder.{3 * li + 1}", train)
+                                 f"encoder.{3 * li}", f"encoder.{3 * li + 1}", train,
+                                 a16=self.x_img if li == 0 else None)
             a = self.enc_a[li][:b]
         ml = self.ml[:b]
         ops.gemm(ml, a, self.W_ml, False, True, bias=self.b_ml)            # mu | log_var, :139
@@ -357,12 +373,13 @@ class GenPass:
     def log_var(self):
         return self.ml[:self.b, self.L:]
 
-    def _bn_linear_bwd(self, d_act, d_h0, h0, act, stats, a_prev, lin, bn, d_prev):
+    def _bn_linear_bwd(self, d_act, d_h0, h0, act, stats, a_prev, lin, bn, d_prev, prev16=None):
         """Backward of Linear -> BatchNorm -> ReLU; d_prev (may be None) receives the input gradient."""
         ops, P, G = self.ops, self.net.P, self.net.G
         ops.bn_bwd(d_h0, d_act, h0, act, None, stats[0], stats[1], P[bn + ".weight"], G[bn + ".weight"],
                    G[bn + ".bias"], True, 0.0)
-        ops.gemm(G[lin + ".weight"], d_h0, a_prev, True, False, accumulate=True)
+        kw = {} if prev16 is None else dict(b16=prev16)
+        ops.gemm(G[lin + ".weight"], d_h0, a_prev, True, False, accumulate=True, **kw)
         # the Linear bias feeds a BatchNorm: its gradient is identically zero and is left at zero
         if d_prev is not None:
             ops.gemm(d_prev, d_h0, P[lin + ".weight"], False, False)
@@ -455,7 +472,8 @@ class GenPass:
             a_prev = self.enc_a[li - 1][:b] if li > 0 else self.x
             d_prev = self.d_act[li - 1][:b] if li > 0 else None
             self._bn_linear_bwd(self.d_act[li][:b], self.d_h0[li][:b], self.enc_h0[li][:b], self.enc_a[li][:b],
-                                self.enc_stats[li], a_prev, f"encoder.{3 * li}", f"encoder.{3 * li + 1}", d_prev)
+                                self.enc_stats[li], a_prev, f"encoder.{3 * li}", f"encoder.{3 * li + 1}", d_prev,
+                                prev16=self.x_img if li == 0 else None)
         if need_dx:
             dx = dx_out if dx_out is not None else ops.zeros(b, self.in_dim)
             ops.gemm(dx, self.d_h0[0][:b], P["encoder.0.weight"], False, False, accumulate=dx_accumulate)
@@ -621,23 +639,24 @@ class CriticStack:
         # the first layer's input [x | emb] as the reference concatenates it (GAN_functions.py:184), so that the
         # layer and its weight gradient are one product each; x and emb are column views
         self.W = in_dim + self.E
-        self.xe = Z(nx * B, _pad4(self.W))
+        Zs = getattr(ops, "shadowed", Z)        # see GenPass: written only through ops wrappers that keep the bf16 image
+        self.xe = Zs(nx * B, _pad4(self.W))     # writers: critic_inputs / copy (gene columns), embed_gather (emb columns)
         self.x = self.xe[:, :in_dim]
         self.emb = self.xe[:, in_dim:self.W]
         self.lab = ops.to_device(torch.zeros(nx * B, getattr(engine, "n_cov", 1), dtype=torch.int64))
-        self.h0, self.a1, self.pm1 = Z(S * B, 1024), Z(S * B, 1024), Z(S * B, 1024)
+        self.h0, self.a1, self.pm1 = Z(S * B, 1024), Zs(S * B, 1024), Z(S * B, 1024)
         self.stats = (Z(S, 1024), Z(S, 1024))
-        self.a2, self.pm2 = Z(S * B, 512), Z(S * B, 512)
-        self.a3, self.pm3 = Z(S * B, 256), Z(S * B, 256)
+        self.a2, self.pm2 = Zs(S * B, 512), Z(S * B, 512)
+        self.a3, self.pm3 = Zs(S * B, 256), Z(S * B, 256)
         self.val = Z(S * B, 1)
         self.dval = Z(S * B, 1)
         self.ones = ops.to_device(torch.ones(B, 1))
-        self.g256, self.g512, self.g1024a, self.g1024b = Z(S * B, 256), Z(S * B, 512), Z(S * B, 1024), Z(S * B, 1024)
-        self.h256, self.h512, self.h1024a, self.h1024b = Z(B, 256), Z(B, 512), Z(B, 1024), Z(B, 1024)
+        self.g256, self.g512, self.g1024a, self.g1024b = Z(S * B, 256), Zs(S * B, 512), Z(S * B, 1024), Zs(S * B, 1024)
+        self.h256, self.h512, self.h1024a, self.h1024b = Z(B, 256), Zs(B, 512), Z(B, 1024), Z(B, 1024)
         self.dsum = Z(B, 1024)
         self.demb = Z(nx * B, self.E)
         self.demb2 = Z(B, self.E)
-        self.uxe = Z(B, _pad4(self.W))          # d(penalty)/d(input gradient) in the gene columns, zeros under emb
+        self.uxe = Zs(B, _pad4(self.W))         # d(penalty)/d(input gradient) in the gene columns, zeros under emb
         self.ux = self.uxe[:, :in_dim]
         self.rowpen = Z(B)
         self.ubar, self.mbar = Z(1024), Z(1024)
@@ -649,7 +668,10 @@ class CriticStack:
     def load(self, i, b, x, labels):
         """Input batch i (x may be None when the rows were written in place through x_seg)."""
         if x is not None:
-            self.x[i * b:(i + 1) * b].copy_(x)
+            if hasattr(self.ops, "copy"):
+                self.ops.copy(self.x[i * b:(i + 1) * b], x)
+            else:
+                self.x[i * b:(i + 1) * b].copy_(x)
         self.have_labels = labels is not None
         if labels is not None:
             self.lab[i * b:(i + 1) * b].copy_(labels)

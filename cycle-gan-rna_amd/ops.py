@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 
 import torch
 
@@ -162,11 +163,56 @@ class HipOps:
                 return sh.data_ptr() + (p - lo) // 2
         return None
 
+    def shadowed(self, *shape):
+        """zeros(*shape) whose bf16 image the kernels of this object keep up to date (bf16 mode; plain zeros
+        otherwise): the wrappers below that write such a tensor - gemm, bn_fwd*, bn_eval, bn_bwd* - hand the kernel the
+        image's address, and gemm reads an operand that has an image from it.  For workspaces that ONLY those
+        wrappers write (an activation or a gradient that the next product reads); a tensor written in any other way
+        must not be made here, its image would go stale."""
+        t = self.zeros(*shape)
+        if self.precision == "bf16" and not os.environ.get("CGRNA_NO_ACT_SHADOWS"):
+            t16 = self.zeros(*shape, dtype=torch.bfloat16)
+            weakref.finalize(t, self.unregister_shadow, self.register_shadow(t.view(-1), t16.view(-1)))
+        return t
+
+    def copy(self, out, x):
+        """out <- x (2-D), keeping the bf16 image of `out` up to date when it has one."""
+        c16, _ = self._twin(out)
+        if c16 is None:
+            out.copy_(x)
+            return
+        M, N = out.shape
+        assert x.shape == out.shape
+        _lib.check(self.lib.cg_copy_bf16(_ptr(out), c16, _ld(out), _ptr(x), _ld(x), M, N, self._stream()), "cg_copy_bf16")
+
+    def image_of(self, x, buf16):
+        """A bf16 image of the float32 matrix `x` for gemm(..., a16= / b16=): the one the backend already keeps if `x`
+        lives in a shadowed workspace, else `x` rounded into the caller's bf16 buffer `buf16` (one launch).  Returns
+        the device address (same leading dimension as `x`, in elements), or None outside bf16 mode."""
+        if self.precision != "bf16" or buf16 is None:
+            return None
+        sp = self._shadow_ptr(x) if self._shadows else None
+        if sp is not None:
+            return sp
+        M, N = x.shape
+        assert buf16.dtype == torch.bfloat16 and buf16.is_contiguous() and buf16.numel() >= M * _ld(x)
+        _lib.check(self.lib.cg_to_bf16(_ptr(buf16), _ld(x), _ptr(x), _ld(x), M, N, self._stream()), "cg_to_bf16")
+        return buf16.data_ptr()
+
+    def _twin(self, t):
+        """(address of the bf16 image of the output view `t`, its leading dimension) for a kernel's bf16-output
+        argument; (None, 0) when `t` has no image."""
+        if not self._shadows:
+            return None, 0
+        sp = self._shadow_ptr(t)
+        return (C.c_void_p(sp), _ld(t)) if sp is not None else (None, 0)
+
     # -- GEMM -----------------------------------------------------------------
     def gemm(self, Cm, A, B, transA=False, transB=False, bias=None, epi=EPI_NONE, E=None, aux=None, slope=0.0,
-             accumulate=False, dtype=None, keep_slabs=False):
+             accumulate=False, dtype=None, keep_slabs=False, a16=None, b16=None):
         """keep_slabs (no epilogue, no accumulation): if the product splits K, leave the partial sums in this
-        stream's scratch for the consumer to add (bn_fwd_slabs) and return their number; 1 = Cm holds the result."""
+        stream's scratch for the consumer to add (bn_fwd_slabs) and return their number; 1 = Cm holds the result.
+        a16 / b16: device address of a bf16 image of A / B (image_of), used when the product runs on the bf16 MFMA."""
         _chk(Cm), _chk(A), _chk(B)
         M, N = Cm.shape
         K = A.shape[0] if transA else A.shape[1]
@@ -182,10 +228,11 @@ class HipOps:
         if dtype is None:
             dtype = 1 if (self.precision == "bf16" and M >= 128 and N >= 128 and K >= 256) else 0
         pA, pB = _ptr(A), _ptr(B)
-        if dtype == 1 and self._shadows:
+        if dtype == 1 and (self._shadows or a16 is not None or b16 is not None):
             # an operand that lives in an arena with a bf16 shadow (the weights) is read from the shadow; the library's
             # conditions: 8-byte aligned rows, even contiguous extent
-            sa, sb = self._shadow_ptr(A), self._shadow_ptr(B)
+            sa = a16 if a16 is not None else self._shadow_ptr(A)
+            sb = b16 if b16 is not None else self._shadow_ptr(B)
             if sb is not None and sb % 8 == 0 and _ld(B) % 4 == 0 and B.shape[1] % 2 == 0 and \
                     (A.data_ptr() % 16 == 0 and _ld(A) % 4 == 0):
                 pB, dtype = C.c_void_p(sb), dtype | 2
@@ -203,9 +250,11 @@ class HipOps:
                                         dtype, _ptr(bias), _ptr(self._ws()[0]), self._ws()[0].numel() * 4,
                                         C.byref(n_slabs), self._stream())
         else:
-            st = self.lib.cg_gemm(_ptr(Cm), _ld(Cm), pA, _ld(A), pB, _ld(B), M, N, K, int(transA), int(transB),
-                                  dtype, _ptr(bias), epi, _ptr(E), _ld(E), _ptr(aux), _ld(aux), float(slope),
-                                  int(accumulate), _ptr(self._ws()[0]), self._ws()[0].numel() * 4, self._stream())
+            c16, _ = self._twin(Cm)
+            st = self.lib.cg_gemm_ex(_ptr(Cm), _ld(Cm), pA, _ld(A), pB, _ld(B), M, N, K, int(transA), int(transB),
+                                     dtype, _ptr(bias), epi, _ptr(E), _ld(E), _ptr(aux), _ld(aux), float(slope),
+                                     int(accumulate), c16, _ptr(self._ws()[0]), self._ws()[0].numel() * 4,
+                                     self._stream())
         if self._gemm_events is not None:
             e1.record(torch.cuda.current_stream(self.device))
             elem = lambda flag: 2.0 if dtype & flag else 4.0  # noqa: E731
@@ -230,7 +279,7 @@ class HipOps:
         assert Y.shape == X.shape and gamma.numel() == N and mean.numel() == N and invstd.numel() == N
         st = self.lib.cg_bn_fwd(_ptr(Y), _ld(Y), _ptr(X), _ld(X), M, N, _ptr(gamma), _ptr(beta), eps, _ptr(mean),
                                 _ptr(invstd), _ptr(rmean), _ptr(rvar), momentum, float(slope), _ptr(mask), _ld(mask),
-                                _ptr(pm), _ld(pm), None, 0, *self._bnws(M, N), self._stream())
+                                _ptr(pm), _ld(pm), *self._twin(Y), *self._bnws(M, N), self._stream())
         _lib.check(st, "cg_bn_fwd")
 
     def bn_slabs_ok(self, M, N):
@@ -247,7 +296,8 @@ class HipOps:
         assert n_slabs >= 1 and n_slabs * M * N <= ws.numel()
         st = self.lib.cg_bn_fwd_slabs(_ptr(Y), _ld(Y), _ptr(X), _ld(X), _ptr(ws), n_slabs, _ptr(x_bias), M, N,
                                       _ptr(gamma), _ptr(beta), eps, _ptr(mean), _ptr(invstd), _ptr(rmean), _ptr(rvar),
-                                      momentum, float(slope), _ptr(mask), _ld(mask), _ptr(pm), _ld(pm), self._stream())
+                                      momentum, float(slope), _ptr(mask), _ld(mask), _ptr(pm), _ld(pm), *self._twin(Y),
+                                      self._stream())
         _lib.check(st, "cg_bn_fwd_slabs")
 
     @staticmethod
@@ -264,7 +314,7 @@ class HipOps:
         assert mean.numel() >= nseg * N and invstd.numel() >= nseg * N and mean.is_contiguous() and invstd.is_contiguous()
         st = self.lib.cg_bn_fwd_seg(_ptr(Y), _ld(Y), _ptr(X), _ld(X), M // nseg, nseg, self._order_code(order, nseg), N,
                                     _ptr(gamma), _ptr(beta), eps, _ptr(mean), _ptr(invstd), _ptr(rmean), _ptr(rvar),
-                                    momentum, float(slope), _ptr(mask), _ld(mask), _ptr(pm), _ld(pm), None, 0,
+                                    momentum, float(slope), _ptr(mask), _ld(mask), _ptr(pm), _ld(pm), *self._twin(Y),
                                     *self._bnws(M // nseg, N, nseg), self._stream())
         _lib.check(st, "cg_bn_fwd_seg")
 
@@ -274,14 +324,14 @@ class HipOps:
         assert mean.numel() >= nseg * N and invstd.numel() >= nseg * N
         st = self.lib.cg_bn_bwd_seg(_ptr(dX), _ld(dX), _ptr(dY), _ld(dY), _ptr(X), _ld(X), _ptr(Y), _ld(Y), _ptr(PM),
                                     _ld(PM), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(dgamma), _ptr(dbeta),
-                                    int(accumulate), None, None, float(slope), M // nseg, nseg, N,
+                                    int(accumulate), None, None, float(slope), M // nseg, nseg, N, *self._twin(dX),
                                     *self._bnws(M // nseg, N, nseg), self._stream())
         _lib.check(st, "cg_bn_bwd_seg")
 
     def bn_eval(self, Y, X, gamma, beta, rmean, rvar, slope, eps=1e-5):
         M, N = X.shape
         st = self.lib.cg_bn_eval(_ptr(Y), _ld(Y), _ptr(X), _ld(X), M, N, _ptr(gamma), _ptr(beta), _ptr(rmean),
-                                 _ptr(rvar), eps, float(slope), self._stream())
+                                 _ptr(rvar), eps, float(slope), *self._twin(Y), self._stream())
         _lib.check(st, "cg_bn_eval")
 
     def bn_bwd(self, dX, dY, X, Y, PM, mean, invstd, gamma, dgamma, dbeta, accumulate, slope, gbar=None, gxbar=None):
@@ -289,8 +339,8 @@ class HipOps:
         assert dX.shape == X.shape and dY.shape == X.shape
         st = self.lib.cg_bn_bwd(_ptr(dX), _ld(dX), _ptr(dY), _ld(dY), _ptr(X), _ld(X), _ptr(Y), _ld(Y), _ptr(PM),
                                 _ld(PM), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(dgamma), _ptr(dbeta),
-                                int(accumulate), _ptr(gbar), _ptr(gxbar), float(slope), M, N, *self._bnws(M, N),
-                                self._stream())
+                                int(accumulate), _ptr(gbar), _ptr(gxbar), float(slope), M, N, *self._twin(dX),
+                                *self._bnws(M, N), self._stream())
         _lib.check(st, "cg_bn_bwd")
 
     def bn_bwd_bwd(self, Vu, Vh, dgamma, accumulate, W, U1, X, mean, invstd, gamma, ubar, mbar):
@@ -326,7 +376,7 @@ class HipOps:
         _chk(labels, torch.int64)
         assert out.shape[1] == E and labels.shape[0] == M and table.is_contiguous()
         st = self.lib.cg_embed_gather(_ptr(out), _ld(out), _ptr(table), E, _ptr(labels), labels.stride(0), M, n_types,
-                                      self._stream())
+                                      self._twin(out)[0], self._stream())
         _lib.check(st, "cg_embed_gather")
 
     def embed_scatter(self, dtable, dout, labels, accumulate):
@@ -380,7 +430,8 @@ class HipOps:
             assert lab_out.shape == (3 * M, n_cov) and real_lab.shape == (M, n_cov) and fake_lab.shape == (M, n_cov)
             assert lab_out.is_contiguous() and real_lab.is_contiguous() and fake_lab.is_contiguous()
         st = self.lib.cg_critic_inputs(_ptr(out), _ld(out), _ptr(real), _ld(real), _ptr(fake), _ld(fake), _ptr(alpha), M,
-                                       G, _ptr(lab_out), _ptr(real_lab), _ptr(fake_lab), n_cov, self._stream())
+                                       G, _ptr(lab_out), _ptr(real_lab), _ptr(fake_lab), n_cov, self._twin(out)[0],
+                                       self._stream())
         _lib.check(st, "cg_critic_inputs")
 
     def interp_hidden(self, H, M, alpha, emb, We):
@@ -400,7 +451,7 @@ class HipOps:
         M, G = UX.shape
         assert V.shape == UX.shape and rowpen.numel() == M
         st = self.lib.cg_gp_penalty(_ptr(V), _ld(V), _ptr(rowpen), _ptr(UX), _ld(UX), float(lambda_gp), M, G,
-                                    self._stream())
+                                    self._twin(V)[0], self._stream())
         _lib.check(st, "cg_gp_penalty")
 
     # -- reductions ---------------------------------------------------------------

@@ -74,6 +74,18 @@ int cg_gemm(float* C, int ldc, const void* A, int lda, const void* B, int ldb,
             float slope, int accumulate, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * cg_gemm that also keeps a bf16 image of its result: every value stored to C (after the epilogue and the
+ * accumulation) is stored, rounded to nearest even, to c_bf16 at the same index (same leading dimension ldc, in
+ * elements; NULL = plain cg_gemm).  The next product of a chain of layers (GAN_functions.py:89-98, 117-125, 165-174
+ * and their gradients) then reads this operand with CG_A_IS_BF16 / CG_B_IS_BF16: half the bytes, no conversion while
+ * staging, the same bits as rounding the float32 values there.
+ */
+int cg_gemm_ex(float* C, int ldc, const void* A, int lda, const void* B, int ldb,
+               int M, int N, int K, int transA, int transB, int dtype,
+               const float* bias, int epi, const float* E, int lde, float* aux, int ldaux,
+               float slope, int accumulate, void* c_bf16, void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * Train-mode BatchNorm1d over the M rows of X (GAN_functions.py:60,63,89,93,
  * 117,121,166) fused with the activation and dropout that follow it
  * (ReLU :61,89,94,117,122; LeakyReLU(0.2)+Dropout(0.3) :167-168):
@@ -112,7 +124,7 @@ int cg_bn_fwd_slabs(float* Y, int ldy, float* X, int ldx, const float* slabs, in
                     int M, int N, const float* gamma, const float* beta, float eps,
                     float* mean_out, float* invstd_out, float* running_mean, float* running_var,
                     float momentum, float slope, const float* mask, int ldmask, float* pm_out, int ldpm,
-                    void* stream);
+                    void* ybf16, int ldybf16, void* stream);
 
 /*
  * cg_bn_fwd for callers that cannot allocate device memory or hand in a workspace (code under HIP graph capture,
@@ -153,10 +165,11 @@ int cg_bn_fwd_seg(float* Y, int ldy, const float* X, int ldx, int seg_rows, int 
 /*
  * Eval-mode BatchNorm1d + activation (g_m2h.eval() translation pass,
  * GAN_functions.py:461-468): Y = act(gamma*(x-rm)/sqrt(rv+eps)+beta).
+ * ybf16 (may be NULL): bf16 image of Y, as in cg_bn_fwd.
  */
 int cg_bn_eval(float* Y, int ldy, const float* X, int ldx, int M, int N,
                const float* gamma, const float* beta, const float* running_mean,
-               const float* running_var, float eps, float slope, void* stream);
+               const float* running_var, float eps, float slope, void* ybf16, int ldybf16, void* stream);
 
 /*
  * Backward of cg_bn_fwd (autograd of the same lines).  g = dY * pm where pm is
@@ -166,13 +179,15 @@ int cg_bn_eval(float* Y, int ldy, const float* X, int ldx, int M, int N,
  * dgamma/dbeta may be NULL (input gradient only); `accumulate` adds into them.
  * gbar_out / gxbar_out (N each, may be NULL) receive mean_m(g), mean_m(g*xhat):
  * the gradient penalty's second-order pass needs them.  dX may alias dY.
+ * dxbf16 (may be NULL): bf16 image of dX (leading dimension lddxbf16), for the weight- and input-gradient
+ * products that read dX next.
  */
 int cg_bn_bwd(float* dX, int lddx, const float* dY, int lddy, const float* X, int ldx,
               const float* Y, int ldy, const float* PM, int ldpm,
               const float* mean, const float* invstd, const float* gamma,
               float* dgamma, float* dbeta, int accumulate,
               float* gbar_out, float* gxbar_out, float slope, int M, int N,
-              void* workspace, size_t workspace_bytes, void* stream);
+              void* dxbf16, int lddxbf16, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * cg_bn_bwd on the `nseg` row segments of a cg_bn_fwd_seg call (mean/invstd
@@ -186,7 +201,7 @@ int cg_bn_bwd_seg(float* dX, int lddx, const float* dY, int lddy, const float* X
                   const float* mean, const float* invstd, const float* gamma,
                   float* dgamma, float* dbeta, int accumulate,
                   float* gbar_out, float* gxbar_out, float slope, int seg_rows, int nseg, int N,
-                  void* workspace, size_t workspace_bytes, void* stream);
+                  void* dxbf16, int lddxbf16, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * BatchNorm backward-of-backward for the gradient penalty
@@ -216,10 +231,14 @@ int cg_mul(float* out, int ldo, const float* x, int ldx, const float* y, int ldy
 int cg_fill_coef(float* out, int ldo, int M, int N, const float* coef, int idx, float scale, void* stream);
 /* float32 -> bf16 (round to nearest even), 2-D. */
 int cg_to_bf16(void* out, int ldo, const float* x, int ldx, int M, int N, void* stream);
+/* out <- x together with its bf16 image out_bf16 (same leading dimension ldo): loading a batch into a workspace
+ * whose image the bf16 products read (the critic's input rows in the generator step, GAN_functions.py:347,366-371). */
+int cg_copy_bf16(float* out, void* out_bf16, int ldo, const float* x, int ldx, int M, int N, void* stream);
 
-/* Embedding lookup (GAN_functions.py:135,181): out[m, 0:E] = table[labels[m*lstride], 0:E]. */
+/* Embedding lookup (GAN_functions.py:135,181): out[m, 0:E] = table[labels[m*lstride], 0:E].
+ * out_bf16 (may be NULL): bf16 image of `out`, same leading dimension. */
 int cg_embed_gather(float* out, int ldo, const float* table, int E, const int64_t* labels, int lstride,
-                    int M, int n_types, void* stream);
+                    int M, int n_types, void* out_bf16, void* stream);
 /* Its gradient: dtable[t, e] (+)= sum over rows with label t of dout[m, e] (deterministic order). */
 int cg_embed_scatter(float* dtable, int E, const float* dout, int lddo, const int64_t* labels, int lstride,
                      int M, int n_types, int accumulate, void* stream);
@@ -254,10 +273,11 @@ int cg_gp_interp(float* out, int ldo, const float* real, int ldr, const float* f
  * The three input batches of a critic step in one pass (:326-336): rows [0, M) of `out` <- real, [M, 2M) <- fake,
  * [2M, 3M) <- alpha*real + (1-alpha)*fake; lab_out (3M x n_cov int64, may be NULL) <- real_lab, fake_lab, fake_lab
  * (the critic sees the generated and the interpolated batch with the labels of the generated one, :328-329).
+ * out_bf16 (may be NULL): bf16 image of `out`, same leading dimension.
  */
 int cg_critic_inputs(float* out, int ldo, const float* real, int ldr, const float* fake, int ldf,
                      const float* alpha, int M, int G, int64_t* lab_out, const int64_t* real_lab,
-                     const int64_t* fake_lab, int n_cov, void* stream);
+                     const int64_t* fake_lab, int n_cov, void* out_bf16, void* stream);
 /*
  * The critic's first Linear (GAN_functions.py:165, on [x | emb], :184) applied to the interpolated batch of the
  * gradient penalty (:196-199) without a product.  The layer is linear and the interpolates are
@@ -273,10 +293,11 @@ int cg_interp_hidden(float* H, int ldh, const float* alpha, const float* emb, in
 /*
  * Row norms and the penalty (:203): n_m = ||UX[m,:]||_2; rowpen[m] = (n_m-1)^2
  * (their mean is the penalty); V[m,:] = (lambda*2/M)*((n_m-1)/n_m)*UX[m,:] is the
- * gradient of lambda*penalty w.r.t. UX.  V may alias UX.
+ * gradient of lambda*penalty w.r.t. UX.  V may alias UX.  v_bf16 (may be NULL): bf16 image of V (leading
+ * dimension ldv) for the two products that read V next.
  */
 int cg_gp_penalty(float* V, int ldv, float* rowpen, const float* UX, int ldu, float lambda_gp,
-                  int M, int G, void* stream);
+                  int M, int G, void* v_bf16, void* stream);
 
 /* ---- reductions / losses ---------------------------------------------------
  * Each reduction writes at most CG_MAX_PARTS float partial sums to

@@ -306,6 +306,35 @@ def test_bf16_mfma_path_within_stated_tolerance():
         assert float(d / exp[i]["fake_human"].double().abs().mean()) <= 1.5e-1, (i, float(d))
 
 
+def test_bf16_images_of_activations_change_no_bit(monkeypatch):
+    """bf16 mode keeps bf16 images of the activations and gradients that products read next (written by the kernel
+    that produces them) instead of rounding the float32 values while they are staged: the same rounding of the same
+    numbers, so parameters and losses after two iterations are equal bit for bit with the images switched off."""
+    from cycle_gan_rna_amd.engine import StepEngine
+    from cycle_gan_rna_amd.noise import HostReplayNoise
+    from cycle_gan_rna_amd.ops import HipOps
+    cfg = O.default_config(preprocess_type="log_normalized", nb_critic=2)
+    nets, xm, xh, lm, lh = make_problem(512, 384, 256, cfg)
+    cm, ch = O.centroid_table(xm, lm, 12), O.centroid_table(xh, lh, 12)
+    data = [t.cuda() for t in (xm, xh, lm[:, None], lh[:, None])]
+    finals = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("CGRNA_NO_ACT_SHADOWS", "1")
+        ops16 = HipOps("cuda:0", precision="bf16")
+        eng = StepEngine(nets, cfg, cm, ch, ops16, 256)
+        n_images = len(ops16._shadows)
+        torch.manual_seed(5)
+        noise = HostReplayNoise(ops16.device)
+        outs = [eng.iteration(i, *data, noise) for i in range(3)]
+        torch.cuda.synchronize()
+        finals.append((eng.arena_g.p.clone(), eng.arena_d.p.clone(), outs[2], n_images))
+    (g0, d0, o0, n0), (g1, d1, o1, n1) = finals
+    assert n0 > n1 == 2, (n0, n1)          # with the switch only the two parameter arenas have images
+    assert torch.equal(g0, g1) and torch.equal(d0, d1)
+    assert all(o0[k] == o1[k] for k in LOSS_KEYS), (o0, o1)
+
+
 class KeyedNoise:
     """Noise whose values depend on what is drawn (kind, shape, how many of that kind and shape came before), not on
     how draws of different kinds interleave: two schedules that keep the order of calls within each kind see the

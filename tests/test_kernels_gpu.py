@@ -656,7 +656,8 @@ def test_token_residual_block_shapes_through_general_kernels(ops, D):
     (512, 12, 1024, 0, 0, EPI_NONE, 0), (1536, 1, 256, 0, 1, EPI_NONE, 0), (1, 256, 1024, 1, 0, EPI_NONE, 1),
     (512, 256, 1, 0, 0, EPI_MUL, 0), (300, 7, 100, 0, 0, EPI_LEAKY, 0), (130, 1024, 12, 0, 1, EPI_NONE, 1),
     (9, 200, 333, 1, 0, EPI_LEAKY, 0), (16, 130, 64, 0, 0, EPI_NONE, 1), (257, 16, 70, 0, 1, EPI_MUL, 0),
-    (5, 3, 2, 1, 1, EPI_NONE, 0)])
+    (5, 3, 2, 1, 1, EPI_NONE, 0), (1024, 12, 1024, 0, 0, EPI_NONE, 0), (100, 3, 1300, 0, 1, EPI_NONE, 1),
+    (7, 16, 600, 0, 0, EPI_MUL, 0), (515, 5, 64, 0, 0, EPI_NONE, 0)])
 def test_gemm_small_dimension_kernels(ops, M, N, K, ta, tb, epi, acc):
     """Products with M, N or K <= 16 take plain-FMA kernels (the critic's head, the embedding slice of its first
     layer, rank-one products): same results and epilogues as the tiled kernel, operands that are column slices."""
@@ -747,3 +748,85 @@ def test_first_layer_on_the_interpolates_by_linearity(ops, M, N, G, E):
     eh[2 * M:] = 9.0
     cpu.interp_hidden(eh, M, alpha, xe[:, G:] if E else None, w1[:, G:] if E else None)
     close(h[2 * M:], eh[2 * M:], 2e-6)
+
+
+def _bf16_ops():
+    from cycle_gan_rna_amd.ops import HipOps
+    return HipOps("cuda:0", precision="bf16")
+
+
+def _image(ops16, t):
+    """The bf16 image the backend keeps of the shadowed float32 tensor `t` (whole tensor)."""
+    p = t.data_ptr()
+    for lo, hi, sh in ops16._shadows:
+        if lo <= p < hi:
+            off = (p - lo) // 4
+            return sh[off:off + t.numel()].view(t.shape)
+    raise AssertionError("tensor has no bf16 image")
+
+
+@pytest.mark.parametrize("M,N,K,ta,tb,epi,acc", [
+    (512, 1024, 2048, 0, 1, EPI_LEAKY, 0),      # tiled kernel, epilogue in the kernel
+    (512, 512, 1024, 0, 1, EPI_NONE, 0),        # split K: the slab reduce writes the image
+    (256, 512, 512, 1, 0, EPI_NONE, 1),         # accumulate
+    (512, 512, 256, 0, 0, EPI_MUL, 0), (130, 70, 300, 0, 1, EPI_NONE, 0), (64, 12, 512, 0, 0, EPI_NONE, 0),
+    (33, 2, 100, 0, 1, EPI_NONE, 0)])
+@pytest.mark.parametrize("dtype", [0, 1])
+def test_gemm_keeps_bf16_image_of_its_result(M, N, K, ta, tb, epi, acc, dtype):
+    """cg_gemm_ex (through HipOps.gemm on a shadowed output): the bf16 image equals the stored float32 result rounded
+    to nearest even, for every kernel that can take the product (tiled float32 / bf16, split-K + reduce, small-dimension
+    kernels) and every epilogue; rows of a row slice outside the product keep their old image."""
+    ops16 = _bf16_ops()
+    full = ops16.shadowed(M + 3, N)
+    assert ops16._shadows, "bf16 mode registers an image"
+    out = full[:M]
+    if acc:
+        out.copy_(dev(rnd(M, N, seed=5)))
+        ops16.refresh_shadow(full.view(-1), _image(ops16, full).view(-1))
+    A = dev(rnd(*((K, M) if ta else (M, K)), seed=1))
+    B = dev(rnd(*((N, K) if tb else (K, N)), seed=2))
+    E = dev((torch.rand(M, N, generator=torch.Generator().manual_seed(4)) < 0.7).float() / 0.7) if epi != EPI_NONE else None
+    aux = torch.empty(M, N).cuda() if epi == EPI_LEAKY else None
+    ops16.gemm(out, A, B, ta, tb, bias=None if acc else dev(rnd(N, seed=3)), epi=epi, E=E, aux=aux, slope=0.2,
+               accumulate=bool(acc), dtype=dtype)
+    torch.cuda.synchronize()
+    img = _image(ops16, full)
+    assert torch.equal(img[:M], out.bfloat16())
+    assert float(img[M:].float().abs().max()) == 0.0          # untouched rows
+    assert float(out.abs().max()) > 0.0
+
+
+@pytest.mark.parametrize("M,N,nseg", [(512, 1024, 1), (100, 300, 1), (600, 256, 1), (96, 1024, 3)])
+def test_batchnorm_kernels_keep_bf16_images(M, N, nseg):
+    """bn_fwd / bn_fwd_seg / bn_fwd_slabs / bn_eval write the bf16 image of the activation and bn_bwd / bn_bwd_seg
+    that of the input gradient (one-launch and two-launch forms): image == float32 output rounded to nearest even."""
+    ops16 = _bf16_ops()
+    R = M * nseg
+    X, dY = dev(rnd(R, N, seed=1)), dev(rnd(R, N, seed=2))
+    gamma, beta = dev(rnd(N, seed=3)), dev(rnd(N, seed=4))
+    mean, invstd = torch.empty(nseg, N).cuda(), torch.empty(nseg, N).cuda()
+    rm, rv = torch.zeros(N).cuda(), torch.ones(N).cuda()
+    Y, dX = ops16.shadowed(R, N), ops16.shadowed(R, N)
+    if nseg == 1:
+        ops16.bn_fwd(Y, X, gamma, beta, mean[0], invstd[0], rm, rv, 0.0)
+    else:
+        ops16.bn_fwd_seg(Y, X, nseg, None, gamma, beta, mean, invstd, rm, rv, 0.2)
+    assert torch.equal(_image(ops16, Y), Y.bfloat16()) and float(Y.abs().max()) > 0
+    dg, db = torch.zeros(N).cuda(), torch.zeros(N).cuda()
+    if nseg == 1:
+        ops16.bn_bwd(dX, dY, X, Y, None, mean[0], invstd[0], gamma, dg, db, True, 0.0)
+    else:
+        ops16.bn_bwd_seg(dX, dY, X, Y, None, nseg, mean, invstd, gamma, dg, db, True, 0.2)
+    assert torch.equal(_image(ops16, dX), dX.bfloat16()) and float(dX.abs().max()) > 0
+    if nseg == 1:
+        Y.zero_()
+        ops16.bn_eval(Y, X, gamma, beta, rm, rv, 0.0)
+        assert torch.equal(_image(ops16, Y), Y.bfloat16()) and float(Y.abs().max()) > 0
+    if nseg == 1 and ops16.bn_slabs_ok(M, N):
+        x, w, bias = dev(rnd(M, 2048, seed=5)), dev(rnd(N, 2048, seed=6) * 0.05), dev(rnd(N, seed=7))
+        H = torch.empty(M, N).cuda()
+        n = ops16.gemm(H, x, w, False, True, bias=bias, keep_slabs=True, dtype=0)
+        if n > 1:
+            Y.zero_()
+            ops16.bn_fwd_slabs(Y, H, n, bias, gamma, beta, mean[0], invstd[0], rm, rv, 0.0)
+            assert torch.equal(_image(ops16, Y), Y.bfloat16()) and float(Y.abs().max()) > 0
