@@ -154,6 +154,11 @@ def main():
     # CGRNA_DDP_ONE_RANK=1: a process group of one rank and the several-rank schedule (RCCL calls between the parts of
     # a step), to exercise that path on a one-GPU machine
     one_rank_group = world == 1 and bool(os.environ.get("CGRNA_DDP_ONE_RANK"))
+    # The collective library prints a version banner on stdout when it starts.  stdout carries the one JSON line and
+    # nothing else: until that line is printed, whatever anything writes to file descriptor 1 goes to stderr.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if one_rank_group:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -359,7 +364,10 @@ def main():
                        "parallelism": f"dp{world}"},
             "roofline": roof, "cpu_baseline": cpu, "bf16_mfma": other, "step_parts": parts,
         }
-        print(json.dumps(line))
+        sys.stdout.flush()
+        os.dup2(json_fd, 1)
+        print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
     if world > 1 or one_rank_group:
         dist.destroy_process_group()
 
