@@ -67,7 +67,7 @@ def measure(reps=2):
 measure(1)
 base = measure(3)
 want = 1 if half else 0
-shapes = sorted((k for k in base if k[6] == want and min(k[0], k[1]) > 2 and k[2] > 16), key=lambda k: -base[k][0] * base[k][1])
+shapes = sorted((k for k in base if (k[6] & 1) == want and min(k[0], k[1]) > 2 and k[2] > 16), key=lambda k: -base[k][0] * base[k][1])
 total_gain = 0.0
 for shape in shapes:
     M, N, K, ta, tb, acc, dt = shape
