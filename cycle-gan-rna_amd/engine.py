@@ -1166,6 +1166,8 @@ class StepEngine(EngineBase):
         self.arena_d.g.zero_()
 
         drawn, self._d_noise = self._d_noise, None
+        if not drawn and getattr(noise, "stacked_draws", False):
+            drawn = self._draw_d_noise(noise, b)
 
         def critic_fwd(name, real, real_lab, fake, fake_lab, s0):
             ds = self.dstack[name]
@@ -1194,7 +1196,15 @@ class StepEngine(EngineBase):
     _d_noise = None      # masks and alpha of the critic step drawn before its critics' part is issued
 
     def _draw_d_noise(self, noise, b):
-        """The critic step's draws in the order of _d_critics (mouse critic, then human critic)."""
+        """The critic step's draws in the order of _d_critics (mouse critic, then human critic).  A source that draws
+        in HBM makes them for both critics at once - one draw for all dropout masks, one for the two alphas: three
+        launches on the stream the critics' branches fork from instead of ten."""
+        if getattr(noise, "stacked_draws", False):
+            n1, n2 = 3 * b * 1024, 3 * b * 512
+            keep = noise.keep((2, n1 + n2), 0.3)
+            alpha = noise.rand((2, b, 1))
+            return {name: (keep[k, :n1].view(3 * b, 1024), keep[k, n1:].view(3 * b, 512), alpha[k])
+                    for k, name in enumerate(("d_m", "d_h"))}
         return {name: self._critic_noise(noise, b, 3, alpha_before=2) for name in ("d_m", "d_h")}
 
     def _d_update(self):
