@@ -407,7 +407,8 @@ __global__ void __launch_bounds__(256) bn_bb_apply(const double* ws, float* Vu, 
                                                    float* dgamma, int accumulate, const float* W, int ldw,
                                                    const float* U1, int ldu, const float* X, int ldx,
                                                    const float* mean, const float* invstd, const float* gamma,
-                                                   const float* ubar, const float* mbar, int M, int N, int rows) {
+                                                   const float* ubar, const float* mbar, int M, int N, int rows,
+                                                   u16* vhbf) {
   __shared__ double lds[3 * RL * CW];
   BN_COMMON
   double s[3];
@@ -426,7 +427,9 @@ __global__ void __launch_bounds__(256) bn_bb_apply(const double* ws, float* Vu, 
     const float u1 = U1[(size_t)m * ldu + col];
     const float xh = (X[(size_t)m * ldx + col] - mu) * is;
     Vu[(size_t)m * ldvu + col] = k1 * (w - wbar - xh * r);
-    Vh[(size_t)m * ldvh + col] = k2 * (mb * (w - wbar) + r * (u1 - ub) + xh * k3);
+    const float vh = k2 * (mb * (w - wbar) + r * (u1 - ub) + xh * k3);
+    Vh[(size_t)m * ldvh + col] = vh;
+    if (vhbf) vhbf[(size_t)m * ldvh + col] = f2bf(vh);
   }
 }
 
@@ -580,7 +583,8 @@ extern "C" int cg_bn_bwd_seg(float* dX, int lddx, const float* dY, int lddy, con
 extern "C" int cg_bn_bwd_bwd(float* V_u1, int ldvu, float* V_h0, int ldvh, float* dgamma, int accumulate,
                              const float* W, int ldw, const float* U1, int ldu, const float* X, int ldx,
                              const float* mean, const float* invstd, const float* gamma, const float* ubar,
-                             const float* mbar, int M, int N, void* workspace, size_t workspace_bytes, void* stream) {
+                             const float* mbar, int M, int N, void* vh_bf16, void* workspace, size_t workspace_bytes,
+                             void* stream) {
   if (!V_u1 || !V_h0 || !W || !U1 || !X || !mean || !invstd || !gamma || !ubar || !mbar || M <= 0 || N <= 0)
     return CG_ERR_BAD_ARG;
   if (ldvu < N || ldvh < N || ldw < N || ldu < N || ldx < N) return CG_ERR_BAD_ARG;
@@ -590,6 +594,7 @@ extern "C" int cg_bn_bwd_bwd(float* V_u1, int ldvu, float* V_h0, int ldvh, float
   hipLaunchKernelGGL(bn_bb_stats, grid, dim3(256), 0, (hipStream_t)stream, (double*)workspace, W, ldw, U1, ldu, X, ldx,
                      mean, invstd, M, N, g.rows);
   hipLaunchKernelGGL(bn_bb_apply, grid, dim3(256), 0, (hipStream_t)stream, (const double*)workspace, V_u1, ldvu, V_h0,
-                     ldvh, dgamma, accumulate, W, ldw, U1, ldu, X, ldx, mean, invstd, gamma, ubar, mbar, M, N, g.rows);
+                     ldvh, dgamma, accumulate, W, ldw, U1, ldu, X, ldx, mean, invstd, gamma, ubar, mbar, M, N, g.rows,
+                     (u16*)vh_bf16);
   return cg_launch_status();
 }

@@ -640,7 +640,9 @@ class CriticStack:
         # layer and its weight gradient are one product each; x and emb are column views
         self.W = in_dim + self.E
         Zs = getattr(ops, "shadowed", Z)        # see GenPass: written only through ops wrappers that keep the bf16 image
-        self.xe = Zs(nx * B, _pad4(self.W))     # writers: critic_inputs / copy (gene columns), embed_gather (emb columns)
+        # writers: critic_inputs / copy (gene columns), embed_gather (emb columns); one more row block after the input
+        # batches for the penalty chain (see gp_backward)
+        self.xe = Zs((nx + 1) * B, _pad4(self.W))
         self.x = self.xe[:, :in_dim]
         self.emb = self.xe[:, in_dim:self.W]
         self.lab = ops.to_device(torch.zeros(nx * B, getattr(engine, "n_cov", 1), dtype=torch.int64))
@@ -651,13 +653,12 @@ class CriticStack:
         self.val = Z(S * B, 1)
         self.dval = Z(S * B, 1)
         self.ones = ops.to_device(torch.ones(B, 1))
-        self.g256, self.g512, self.g1024a, self.g1024b = Z(S * B, 256), Zs(S * B, 512), Z(S * B, 1024), Zs(S * B, 1024)
+        self.g256, self.g512, self.g1024a, self.g1024b = Z(S * B, 256), Zs(S * B, 512), Z(S * B, 1024), Zs((S + 1) * B, 1024)
         self.h256, self.h512, self.h1024a, self.h1024b = Z(B, 256), Zs(B, 512), Z(B, 1024), Z(B, 1024)
         self.dsum = Z(B, 1024)
         self.demb = Z(nx * B, self.E)
         self.demb2 = Z(B, self.E)
-        self.uxe = Zs(B, _pad4(self.W))         # d(penalty)/d(input gradient) in the gene columns, zeros under emb
-        self.ux = self.uxe[:, :in_dim]
+        self.zero_emb = Z(B, max(self.E, 1))
         self.rowpen = Z(B)
         self.ubar, self.mbar = Z(1024), Z(1024)
         self.b, self.have_labels = 0, True
@@ -769,33 +770,46 @@ class CriticStack:
         ops.gemm(dx_out, dsum, P["model.0.weight"][:, :Gd], False, False, accumulate=True)
 
     def gp_backward(self, b, seg, lambda_gp, red, slot):
-        """Segment `seg` holds the forward on the interpolates: first-order chain to the input gradient, the
-        penalty (row terms reduced into `slot`), and the second-order chain accumulating
+        """Segment `seg` (the last one) holds the forward on the interpolates: first-order chain to the input
+        gradient, the penalty (row terms reduced into `slot`), and the second-order chain accumulating
         d(lambda*penalty)/d(params)  (GAN_functions.py:194-204, :336-339).  The parameter gradients go to the
         network's second gradient buffer, each tensor overwritten on first touch (the tensors this chain never
-        touches - biases - stay zero there), so the chain can run beside backward_params."""
+        touches - biases - stay zero there), so the chain can run beside backward_params.
+
+        The first layer's weight gradient has two terms, vh0^T x_interp and u0^T V (V = d(penalty)/d(input gradient),
+        zeros under the embedding columns).  They are one product with twice the reduction length: vh0 and u0 are
+        written into adjacent row blocks of the hidden-gradient workspace, [vh0; u0], and V into the row block of the
+        stacked input that follows the interpolates, [x_interp; V] - one launch and one pass over the 20 MB gradient
+        instead of a product that writes it and a second one that reads, adds and writes it."""
         ops, P, G, Gd = self.ops, self.net.P, self.net.G2, self.Gd
-        sl = slice(seg * b, (seg + 1) * b)
+        assert seg == self.S - 1 == self.nx - 1
+        sl, nxt = slice(seg * b, (seg + 1) * b), slice((seg + 1) * b, (seg + 2) * b)
         mean, invstd = self.stats[0][seg], self.stats[1][seg]
-        h0, pm1, pm2, pm3, xe = self.h0[sl], self.pm1[sl], self.pm2[sl], self.pm3[sl], self.xe[sl, :self.W]
+        h0, pm1, pm2, pm3 = self.h0[sl], self.pm1[sl], self.pm2[sl], self.pm3[sl]
         W1, W2, W3, w4 = P["model.0.weight"], P["model.4.weight"], P["model.7.weight"], P["model.9.weight"]
-        u3, u2, u1, u0 = self.g256[sl], self.g512[sl], self.g1024a[sl], self.g1024b[sl]
+        u3, u2, u1 = self.g256[sl], self.g512[sl], self.g1024a[sl]
+        vh0, u0 = self.g1024b[sl], self.g1024b[nxt]
+        ux = self.xe[nxt, :Gd]
+        if self.E:      # V is zero under the embedding columns; a batch of another size leaves other rows' values there
+            if hasattr(ops, "copy"):
+                ops.copy(self.xe[nxt, Gd:self.W], self.zero_emb[:b])
+            else:
+                self.xe[nxt, Gd:self.W].zero_()
         ops.gemm(u3, self.ones[:b], w4, False, False, epi=EPI_MUL, E=pm3)
         ops.gemm(u2, u3, W3, False, False, epi=EPI_MUL, E=pm2)
         ops.gemm(u1, u2, W2, False, False, epi=EPI_MUL, E=pm1)
         ops.bn_bwd(u0, u1, h0, None, None, mean, invstd, P["model.1.weight"], None, None, False, 1.0, self.ubar,
                    self.mbar)
-        ux = self.ux[:b]
         ops.gemm(ux, u0, W1[:, :Gd], False, False)
         ops.gp_penalty(ux, self.rowpen[:b], ux, lambda_gp)          # ux now holds V
         ops.reduce_sum(red, slot, self.rowpen[:b])
-        gW1 = G["model.0.weight"]
-        ops.gemm(gW1, u0, self.uxe[:b, :self.W], True, False)       # first touch: all columns (zeros under emb)
         w = self.h1024a[:b]
         ops.gemm(w, ux, W1[:, :Gd], False, True)
-        vu1, vh0 = self.h1024b[:b], self.h1024a[:b]
+        vu1 = self.h1024b[:b]
         ops.bn_bwd_bwd(vu1, vh0, G["model.1.weight"], False, w, u1, h0, mean, invstd, P["model.1.weight"], self.ubar,
                        self.mbar)
+        ops.gemm(G["model.0.weight"], self.g1024b[seg * b:(seg + 2) * b], self.xe[seg * b:(seg + 2) * b, :self.W],
+                 True, False)               # first touch: all columns
         t1 = vu1
         ops.mul(t1, vu1, pm1)
         ops.gemm(G["model.4.weight"], u2, t1, True, False)
@@ -805,7 +819,6 @@ class CriticStack:
         vu3 = self.h256[:b]
         ops.gemm(vu3, t2, W3, False, True, epi=EPI_MUL, E=pm3)
         ops.colsum(G["model.9.weight"], vu3, 1.0, False)
-        ops.gemm(gW1, vh0, xe, True, False, accumulate=True)
         if self.have_labels:
             ops.gemm(self.demb2[:b], vh0, W1[:, Gd:], False, False)
             _embed_scatter(ops, G, self.demb2[:b], self.lab[sl], False)

@@ -348,7 +348,7 @@ class HipOps:
         assert Vu.shape == X.shape and Vh.shape == X.shape and W.shape == X.shape and U1.shape == X.shape
         st = self.lib.cg_bn_bwd_bwd(_ptr(Vu), _ld(Vu), _ptr(Vh), _ld(Vh), _ptr(dgamma), int(accumulate), _ptr(W),
                                     _ld(W), _ptr(U1), _ld(U1), _ptr(X), _ld(X), _ptr(mean), _ptr(invstd), _ptr(gamma),
-                                    _ptr(ubar), _ptr(mbar), M, N, *self._bnws(M, N), self._stream())
+                                    _ptr(ubar), _ptr(mbar), M, N, self._twin(Vh)[0], *self._bnws(M, N), self._stream())
         _lib.check(st, "cg_bn_bwd_bwd")
 
     # -- elementwise ------------------------------------------------------------

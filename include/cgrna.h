@@ -213,11 +213,12 @@ int cg_bn_bwd_seg(float* dX, int lddx, const float* dY, int lddy, const float* X
  *   V_u1 = invstd*gamma*(W - wbar - xhat*r)
  *   V_h0 = -invstd^2*gamma*( m*(W-wbar) + r*(u1-ubar) + xhat*(q - wbar*ubar - 3*m*r) )
  *   dgamma (+)= M*invstd*(q - wbar*ubar - r*m)
+ * vh_bf16 (may be NULL): bf16 image of V_h0 (leading dimension ldvh) for the weight-gradient product that reads it.
  */
 int cg_bn_bwd_bwd(float* V_u1, int ldvu, float* V_h0, int ldvh, float* dgamma, int accumulate,
                   const float* W, int ldw, const float* U1, int ldu, const float* X, int ldx,
                   const float* mean, const float* invstd, const float* gamma,
-                  const float* ubar, const float* mbar, int M, int N,
+                  const float* ubar, const float* mbar, int M, int N, void* vh_bf16,
                   void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- elementwise / gather ------------------------------------------------ */
