@@ -1050,7 +1050,7 @@ class StepEngine(EngineBase):
         self.d_slots = ops.to_device(torch.arange(6, dtype=torch.int32))
         self.d_scales = Z(6, dtype=torch.float64)
         self.var_out = Z(2)
-        self.var_ws = Z(max((max(gm, gh) + 31) // 32, 1), dtype=torch.float64)
+        self.var_ws = [Z(max((max(gm, gh) + 31) // 32, 1), dtype=torch.float64) for _ in range(2)]
         self._d_scales_b = None
         self.d_feat2 = Z(B, 256)
         from .ddp import GradSync
@@ -1176,7 +1176,6 @@ class StepEngine(EngineBase):
         ops, cfg = self.ops, self.cfg
         mouse, human, mouse_cat, human_cat, noise, fake_human, fake_mouse = self._d_state
         b = mouse.shape[0]
-        self.arena_d.g.zero_()
 
         drawn, self._d_noise = self._d_noise, None
         if not drawn and getattr(noise, "stacked_draws", False):
@@ -1199,9 +1198,12 @@ class StepEngine(EngineBase):
         # arena, penalty (double backward on the interpolates) into the second gradient buffer.  (Measured: one
         # branch per critic - forward, then both chains one after the other - takes the same time, 2.98 ms per
         # iteration either way: the step is bound by what its kernels take, not by how many run side by side.)
-        self._many(lambda: self.dstack["d_m"].backward_params(b, (-1.0 / b, 1.0 / b)),
+        def wasserstein(name):      # each critic's gradients are cleared in the branch that accumulates into them
+            self.arena_d.net_grad(name).zero_()
+            self.dstack[name].backward_params(b, (-1.0 / b, 1.0 / b))
+        self._many(lambda: wasserstein("d_m"),
                    lambda: self.dstack["d_m"].gp_backward(b, 2, cfg["lambda_gp"], self.red, S_DM_REAL + 2),
-                   lambda: self.dstack["d_h"].backward_params(b, (-1.0 / b, 1.0 / b)),
+                   lambda: wasserstein("d_h"),
                    lambda: self.dstack["d_h"].gp_backward(b, 2, cfg["lambda_gp"], self.red, S_DH_REAL + 2))
         self.arena_d.g.add_(self.arena_d.g2)
         ops.sum_parts(self.d_tot, self.red, self.d_slots, self.d_scales)
@@ -1294,7 +1296,7 @@ class StepEngine(EngineBase):
                     o["ih"] = self.gen_i["g_m2h"].forward(human, human_cat, noise)
                     ops.reduce_l1(red, S_IDT_H, o["ih"], human)
 
-        def critics(name, fake, real, lab, cents, src_lab, s_adv, s_ct, m_real, m_fake, s_fm, gen_first, s_kl):
+        def critics(name, fake, real, lab, cents, src_lab, s_adv, s_ct, m_real, m_fake, s_fm, gen_first, s_kl, k_var):
             # segments: adversarial call on the generated batch (:347) | feature call on it (:368,:371) | feature
             # call on the real batch (:367,:370); the reference makes them in the order 0, 2, 1
             gs = self.gstack[name]
@@ -1308,13 +1310,16 @@ class StepEngine(EngineBase):
             ops.colsum(self.fm_mean[m_fake], feat[b:2 * b], 1.0 / b)
             ops.reduce_sqdiff(red, s_fm, self.fm_mean[m_real], self.fm_mean[m_fake])
             ops.reduce_kl(red, s_kl, gen_first.ml[:b])                      # :375-376
+            # the recorded variance of the generated batch (:418-419) needs nothing but that batch: computed in this
+            # branch instead of after the optimizer step, where it would run alone
+            ops.colvar_mean(self.var_out[k_var:k_var + 1], self.var_ws[k_var], fake)
         # the cycle passes and the critic calls only need the generated batches: four independent branches
         self._many(lambda: cyc("rm", Rm, fake_human, human_cat, mouse, S_CYC_M),
                    lambda: cyc("rh", Rh, fake_mouse, mouse_cat, human, S_CYC_H),
                    lambda: critics("d_h", fake_human, human, human_cat, self.human_centroids, mouse_cat, S_ADV_H, S_CT_H,
-                                   "h_real", "h_fake", S_FM_H, A, S_KL_H),
+                                   "h_real", "h_fake", S_FM_H, A, S_KL_H, 0),
                    lambda: critics("d_m", fake_mouse, mouse, mouse_cat, self.mouse_centroids, human_cat, S_ADV_M, S_CT_M,
-                                   "m_real", "m_fake", S_FM_M, Bp, S_KL_M))
+                                   "m_real", "m_fake", S_FM_M, Bp, S_KL_M, 1))
         if self.sync.enabled:
             ops.sum_parts(self.g_tot, red, self.g_slots, self.g_ones)
 
@@ -1378,12 +1383,15 @@ class StepEngine(EngineBase):
                    lambda: crit(dfm, fake_mouse, self.mouse_centroids, human_cat, gm, self.gstack["d_m"], "m_fake",
                                 "m_real", self.d_feat2[:b]),
                    lambda: cycb(self.d_recov["human"][:b], recov_human, human, gh, Rh, dcm))
-        ops.axpby(dfh, 1.0, dfh, 1.0, dch)
-        ops.axpby(dfm, 1.0, dfm, 1.0, dcm)
-        if self.sync.enabled:       # the first passes' backward in two halves with a collective launched between
-            self._two(lambda: A.backward_decoder(dfh), lambda: Bp.backward_decoder(dfm))
-        else:
-            self._two(lambda: A.backward(dfh, kl=(coef, 4, 1.0)), lambda: Bp.backward(dfm, kl=(coef, 4, 1.0)))
+        def first(p, dfake, dcyc, whole):      # each side adds its cycle term inside its own branch
+            ops.axpby(dfake, 1.0, dfake, 1.0, dcyc)
+            if whole:
+                p.backward(dfake, kl=(coef, 4, 1.0))
+            else:
+                p.backward_decoder(dfake)
+        # several ranks: the first passes' backward in two halves with a collective launched between
+        whole = not self.sync.enabled
+        self._two(lambda: first(A, dfh, dch, whole), lambda: first(Bp, dfm, dcm, whole))
 
     def _g_backward_rest(self):
         A, Bp = self.gen_a["g_m2h"], self.gen_a["g_h2m"]
@@ -1415,8 +1423,6 @@ class StepEngine(EngineBase):
         o = self._g_state[4]
         fake_human, fake_mouse = o["fh"], o["fm"]
         self._adam(self.arena_g)
-        ops.colvar_mean(self.var_out[0:1], self.var_ws, fake_human)        # :418-419
-        ops.colvar_mean(self.var_out[1:2], self.var_ws, fake_mouse)
         self.fake_human, self.fake_mouse = fake_human, fake_mouse
 
     def set_loss_weights(self, weights):
