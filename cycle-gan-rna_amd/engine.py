@@ -1256,7 +1256,6 @@ class StepEngine(EngineBase):
         self._d_pending_lr = None
 
     def _g_first(self, mouse, human, mouse_cat, human_cat, noise):
-        self.arena_g.g.zero_()
         A, Bp = self.gen_a["g_m2h"], self.gen_a["g_h2m"]
         o = {}
         # Forward, in the reference's call order (:344-372).  Each pair below is independent and may run on two
@@ -1299,6 +1298,8 @@ class StepEngine(EngineBase):
         def critics(name, fake, real, lab, cents, src_lab, s_adv, s_ct, m_real, m_fake, s_fm, gen_first, s_kl, k_var):
             # segments: adversarial call on the generated batch (:347) | feature call on it (:368,:371) | feature
             # call on the real batch (:367,:370); the reference makes them in the order 0, 2, 1
+            if k_var == 0:      # the generators' gradients are cleared here, beside the forward passes: nothing adds to
+                self.arena_g.g.zero_()                                  # them before the backward pass
             gs = self.gstack[name]
             gs.load(0, b, fake, lab)
             gs.load(1, b, real, lab)
@@ -1576,8 +1577,6 @@ class StepEngine(EngineBase):
                 self._after(st, main)
             passes = self.gen_a if mode == "g" else self.gen_d[1 - s]
             with self._Lane(self, noise, lanes[0]):
-                if mode == "g":
-                    self.arena_g.g.zero_()
                 out_h = passes["g_m2h"].forward(mouse, mouse_cat, noise)
             with self._Lane(self, noise, lanes[1]):
                 out_m = passes["g_h2m"].forward(human, human_cat, noise)

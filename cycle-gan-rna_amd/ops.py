@@ -8,6 +8,7 @@ file, and there is no fallback when the library or the GPU is missing.
 """
 from __future__ import annotations
 
+import bisect
 import ctypes as C
 import os
 import weakref
@@ -69,6 +70,7 @@ class HipOps:
         self._scratch = {}
         # float32 arenas that have a bf16 shadow: (first byte, one past the last byte, shadow tensor)
         self._shadows = []
+        self._shadow_los = []
 
     def _ws(self):
         key = torch.cuda.current_stream(self.device).cuda_stream
@@ -142,6 +144,8 @@ class HipOps:
         assert f32_flat.is_contiguous() and bf16_flat.is_contiguous() and f32_flat.numel() == bf16_flat.numel()
         assert bf16_flat.dtype == torch.bfloat16 and bf16_flat.data_ptr() % 16 == 0 and f32_flat.data_ptr() % 16 == 0
         self._shadows.append((f32_flat.data_ptr(), f32_flat.data_ptr() + 4 * f32_flat.numel(), bf16_flat))
+        self._shadows.sort(key=lambda e: e[0])          # address ranges are disjoint: looked up by bisection
+        self._shadow_los = [e[0] for e in self._shadows]
         self.refresh_shadow(f32_flat, bf16_flat)
         return f32_flat.data_ptr()
 
@@ -149,6 +153,7 @@ class HipOps:
         """Forget the shadow registered for the arena at address `key` (its owner is gone; the address range may be
         handed to another tensor)."""
         self._shadows = [e for e in self._shadows if e[0] != key]
+        self._shadow_los = [e[0] for e in self._shadows]
 
     def refresh_shadow(self, f32_flat, bf16_flat):
         n = f32_flat.numel()
@@ -158,8 +163,10 @@ class HipOps:
     def _shadow_ptr(self, t):
         """Device address of the bf16 image of the float32 view `t` (same leading dimension, in elements), or None."""
         p = t.data_ptr()
-        for lo, hi, sh in self._shadows:
-            if lo <= p < hi:
+        i = bisect.bisect_right(self._shadow_los, p) - 1
+        if i >= 0:
+            lo, hi, sh = self._shadows[i]
+            if p < hi:
                 return sh.data_ptr() + (p - lo) // 2
         return None
 
