@@ -54,6 +54,17 @@ class GlobalRngNoise:
         return torch.rand(shape)
 
 
+class WideNoise(GlobalRngNoise):
+    """The float32 draws of GlobalRngNoise, widened: a float64 run of the oracle sees the same noise values as a
+    float32 run (and as the reference) after the same torch.manual_seed."""
+
+    def randn(self, shape, dtype):
+        return torch.randn(shape, dtype=torch.float32).to(dtype)
+
+    def keep(self, shape, p_drop, dtype):
+        return super().keep(shape, p_drop, torch.float32).to(dtype)
+
+
 class GeneratorNoise:
     """GlobalRngNoise drawing from a generator of its own: after Generator().manual_seed(s) it sees the numbers the
     global generator gives after torch.manual_seed(s), so several replicas of the step (one per emulated rank) can

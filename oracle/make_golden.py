@@ -307,7 +307,21 @@ def trajectory_level(R):
     ref, nets, data, metrics = run_reference_function(R, cfg, 2000, 2000, 512, init_seed=0, data_seed=1234, train_seed=1)
     tr, metrics2 = run_oracle_function(nets, cfg, data, train_seed=1)
     compare_function("traj", ref, tr, metrics, metrics2)
+    # the same run of the oracle in float64 on the same (float32-drawn) noise: the arbiter between float32
+    # implementations, whose trajectories drift apart by amplified rounding
+    cast = lambda t: t.double() if t.is_floating_point() else t  # noqa: E731
+    xm, lm, xh, lh = data
+    tr64 = O.OracleTrainer({n: {k: cast(v) for k, v in sd.items()} for n, sd in nets.items()}, cfg,
+                           O.centroid_table(xm, lm, 12).double(), O.centroid_table(xh, lh, 12).double(),
+                           noise=O.WideNoise())
+    torch.manual_seed(1)
+    metrics64 = oracle_train(tr64, xm.double(), xh.double(), lm[:, None], lh[:, None], cfg)
+    e_ref = {k: relerr(metrics64[k], [float(v) for v in metrics[k]]) for k in metrics}
+    e_orc = {k: relerr(metrics64[k], metrics2[k]) for k in metrics}
+    print("[traj] against the float64 oracle: reference max rel err %.3e, float32 oracle %.3e"
+          % (max(e_ref.values()), max(e_orc.values())))
     fx = dict(torch_version=str(torch.__version__), cfg={k: v for k, v in cfg.items() if k != 'device'},
+              oracle_metrics_f64={k: [float(v) for v in vals] for k, vals in metrics64.items()},
               g_mouse=2000, g_human=2000, N=512, init_seed=0, data_seed=1234, train_seed=1,
               metrics={k: [float(v) for v in vals] for k, vals in metrics.items()},
               # the float32 oracle on the same seeds: the gap between two CPU float32

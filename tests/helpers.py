@@ -40,14 +40,7 @@ LOSS_KEYS = ('d_m_loss', 'd_h_loss', 'g_loss', 'g_adv', 'cycle_loss', 'celltype_
              'fake_human_var', 'fake_mouse_var')
 
 
-class _WideNoise(O.GlobalRngNoise):
-    """The float32 draws of GlobalRngNoise, widened: a float64 run of the oracle sees the same noise values."""
-
-    def randn(self, shape, dtype):
-        return torch.randn(shape, dtype=torch.float32).to(dtype)
-
-    def keep(self, shape, p_drop, dtype):
-        return super().keep(shape, p_drop, torch.float32).to(dtype)
+_WideNoise = O.WideNoise
 
 
 def oracle_iteration_grads(nets, cfg, cm, ch, xm, xh, lm, lh, dtype, seed):
