@@ -143,13 +143,17 @@ def test_two_ranks_match_gradient_averaging_oracle(tmp_path):
             assert update_rel_l2(v[mask], ref[mask], init[mask]) <= bound, (n, k)
 
 
-def _bench_line(cmd, env, timeout):
+def _bench_line(cmd, env, timeout, only_line=False):
+    """only_line: stdout must consist of the JSON line and nothing else (a launcher's own chatter aside, a driver
+    that reads stdout must not find a library's banner in front of the line)."""
     import json
     import subprocess
     p = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, p.stdout
+    if only_line:
+        assert p.stdout.strip().splitlines() == lines, p.stdout
     return json.loads(lines[0])
 
 
@@ -192,5 +196,5 @@ def test_several_rank_schedule_over_rccl_with_one_rank():
     for extra in ([], ["--eager"]):
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "6", "--warmup", "2", "--no-roofline",
                "--no-cpu-baseline", "--no-bf16-line"] + extra
-        out = _bench_line(cmd, env, 200)
+        out = _bench_line(cmd, env, 200, only_line=True)      # RCCL prints a version banner when it starts
         assert out["n_gpus"] == 1 and out["value"] > 0
