@@ -167,17 +167,17 @@ __global__ void gp_interp_kernel(float* out, int ldo, const float* real, int ldr
 // interpolates; and their labels (n_cov int64 per row): real's, fake's, fake's.
 __global__ void critic_inputs_kernel(float* out, int ldo, const float* real, int ldr, const float* fake, int ldf,
                                      const float* alpha, int M, int G, int64_t* lab_out, const int64_t* real_lab,
-                                     const int64_t* fake_lab, int n_cov, u16* out16) {
+                                     const int64_t* fake_lab, int n_cov, u16* out16, int ib) {
   CG_2D_LOOP(M, G) {
     const float a = alpha[m], r = real[(size_t)m * ldr + col], f = fake[(size_t)m * ldf + col];
     const float x = a * r + (1.f - a) * f;
     out[(size_t)m * ldo + col] = r;
     out[(size_t)(M + m) * ldo + col] = f;
-    out[(size_t)(2 * M + m) * ldo + col] = x;
+    out[((size_t)ib * M + m) * ldo + col] = x;
     if (out16) {
       out16[(size_t)m * ldo + col] = f2bf(r);
       out16[(size_t)(M + m) * ldo + col] = f2bf(f);
-      out16[(size_t)(2 * M + m) * ldo + col] = f2bf(x);
+      out16[((size_t)ib * M + m) * ldo + col] = f2bf(x);
     }
   }
   if (lab_out && blockIdx.x == 0 && blockIdx.y == 0) {
@@ -207,6 +207,29 @@ __global__ void interp_hidden_kernel(float* H, int ldh, const float* alpha, cons
     }
     H[(size_t)(2 * M + m) * ldh + col] = v;
   }
+}
+
+// The penalty's weight-gradient term vh0^T x_interp folded into the Wasserstein terms (see cg_gp_combine): in place,
+// D[m] += a_m VH[m] (real rows), D[M + m] += (1 - a_m) VH[m] (generated rows); AV[m] = a_m VH[m]; and, by the first
+// column block, dE[m] = emb[M + m] - emb[m].
+__global__ void gp_combine_kernel(float* D, int ldd, const float* VH, int ldv, const float* alpha, float* AV, int ldav,
+                                  const float* emb, int lde, int E, float* dE, int ldde, int M, int N, u16* D16) {
+  CG_2D_LOOP(M, N) {
+    const float a = alpha[m], v = VH[(size_t)m * ldv + col];
+    const float av = a * v;
+    const float p = D[(size_t)m * ldd + col] + av;
+    const float q = D[(size_t)(M + m) * ldd + col] + (v - av);
+    D[(size_t)m * ldd + col] = p;
+    D[(size_t)(M + m) * ldd + col] = q;
+    AV[(size_t)m * ldav + col] = av;
+    if (D16) {
+      D16[(size_t)m * ldd + col] = f2bf(p);
+      D16[(size_t)(M + m) * ldd + col] = f2bf(q);
+    }
+  }
+  if (emb && blockIdx.x == 0 && (int)threadIdx.x < E)
+    for (int m = blockIdx.y; m < M; m += gridDim.y)
+      dE[(size_t)m * ldde + threadIdx.x] = emb[(size_t)(M + m) * lde + threadIdx.x] - emb[(size_t)m * lde + threadIdx.x];
 }
 
 __global__ void __launch_bounds__(256) gp_penalty_kernel(float* V, int ldv, float* rowpen, const float* UX, int ldu,
@@ -573,12 +596,13 @@ extern "C" int cg_gp_interp(float* out, int ldo, const float* real, int ldr, con
 
 extern "C" int cg_critic_inputs(float* out, int ldo, const float* real, int ldr, const float* fake, int ldf,
                                 const float* alpha, int M, int G, int64_t* lab_out, const int64_t* real_lab,
-                                const int64_t* fake_lab, int n_cov, void* out_bf16, void* stream) {
+                                const int64_t* fake_lab, int n_cov, int interp_block, void* out_bf16, void* stream) {
   if (!out || !real || !fake || !alpha || M <= 0 || G <= 0 || ldo < G || ldr < G || ldf < G) return CG_ERR_BAD_ARG;
+  if (interp_block < 2) return CG_ERR_BAD_ARG;
   if (lab_out && (!real_lab || !fake_lab || n_cov <= 0)) return CG_ERR_BAD_ARG;
   Grid2 g = grid2(M, G);
   hipLaunchKernelGGL(critic_inputs_kernel, g.grid, g.block, 0, ST, out, ldo, real, ldr, fake, ldf, alpha, M, G, lab_out,
-                     real_lab, fake_lab, n_cov, (u16*)out_bf16);
+                     real_lab, fake_lab, n_cov, (u16*)out_bf16, interp_block);
   return cg_launch_status();
 }
 
@@ -588,6 +612,17 @@ extern "C" int cg_interp_hidden(float* H, int ldh, const float* alpha, const flo
   if (emb && (!We || E <= 0 || lde < E || ldw < E)) return CG_ERR_BAD_ARG;
   Grid2 g = grid2(M, N);
   hipLaunchKernelGGL(interp_hidden_kernel, g.grid, g.block, 0, ST, H, ldh, alpha, emb, lde, E, We, ldw, M, N);
+  return cg_launch_status();
+}
+
+extern "C" int cg_gp_combine(float* D, int ldd, const float* VH, int ldv, const float* alpha, float* AV, int ldav,
+                             const float* emb, int lde, int E, float* dE, int ldde, int M, int N, void* d_bf16,
+                             void* stream) {
+  if (!D || !VH || !alpha || !AV || M <= 0 || N <= 0 || ldd < N || ldv < N || ldav < N) return CG_ERR_BAD_ARG;
+  if (emb && (!dE || E <= 0 || E > 256 || lde < E || ldde < E)) return CG_ERR_BAD_ARG;
+  Grid2 g = grid2(M, N);
+  hipLaunchKernelGGL(gp_combine_kernel, g.grid, g.block, 0, ST, D, ldd, VH, ldv, alpha, AV, ldav, emb, lde, E, dE, ldde,
+                     M, N, (u16*)d_bf16);
   return cg_launch_status();
 }
 

@@ -629,7 +629,12 @@ class CriticStack:
 
     nseg: segments of the hidden activations; nx: distinct input batches.  With nx < nseg the first input feeds
     segments 0..nseg-nx (the generator step looks at the same generated batch twice), the others one segment each.
-    Segments are packed at stride b (the current batch size), so ragged batches stay contiguous."""
+    Segments are packed at stride b (the current batch size), so ragged batches stay contiguous.
+
+    The critic step's stack (nseg = nx = 3: real | generated | interpolated) keeps one row block more in two
+    workspaces, laid out so that the whole gradient of the first layer's weight is ONE product over three row blocks
+    (w1_grad): the stacked input holds [x_real; x_generated; V; x_interp] and the hidden-gradient workspace
+    [dh0_real; dh0_generated; u0; vh0]."""
 
     def __init__(self, engine, net: Net, in_dim, max_b, nseg, nx):
         ops = engine.ops
@@ -640,8 +645,8 @@ class CriticStack:
         # layer and its weight gradient are one product each; x and emb are column views
         self.W = in_dim + self.E
         Zs = getattr(ops, "shadowed", Z)        # see GenPass: written only through ops wrappers that keep the bf16 image
-        # writers: critic_inputs / copy (gene columns), embed_gather (emb columns); one more row block after the input
-        # batches for the penalty chain (see gp_backward)
+        # writers: critic_inputs / copy / gp_penalty (gene columns), embed_gather / copy (emb columns)
+        self.gp_layout = nseg == 3 and nx == 3      # the critic step's stack: see the class docstring
         self.xe = Zs((nx + 1) * B, _pad4(self.W))
         self.x = self.xe[:, :in_dim]
         self.emb = self.xe[:, in_dim:self.W]
@@ -659,6 +664,8 @@ class CriticStack:
         self.demb = Z(nx * B, self.E)
         self.demb2 = Z(B, self.E)
         self.zero_emb = Z(B, max(self.E, 1))
+        self.demb_diff = Z(B, max(self.E, 1))
+        self.alpha = None                       # the interpolation weights of the current critic step (forward)
         self.rowpen = Z(B)
         self.ubar, self.mbar = Z(1024), Z(1024)
         self.b, self.have_labels = 0, True
@@ -688,17 +695,24 @@ class CriticStack:
         self.b = b
         R, Rx, off = S * b, nx * b, (S - nx) * b
         W1 = P["model.0.weight"]
-        x, emb = self.x[:Rx], self.emb[:Rx]
-        if self.have_labels:
-            _embed_gather(ops, emb, P, self.lab[:Rx])
-        else:
-            emb.zero_()
+        if interp is not None:
+            self.alpha = interp
+        # row blocks of the stacked input that hold input batches: 0, 1 and - in the critic step's layout - 3
+        blocks = [(0, 2 * b, 0), (3 * b, 4 * b, 2 * b)] if self.gp_layout else [(0, Rx, 0)]
+        for lo, hi, lab0 in blocks:
+            if self.have_labels:
+                _embed_gather(ops, self.emb[lo:hi], P, self.lab[lab0:lab0 + hi - lo])
+            else:
+                self.emb[lo:hi].zero_()
         h0 = self.h0[:R]
         if interp is not None:
-            assert S == 3 and nx == 3
+            assert self.gp_layout
             ops.gemm(h0[:2 * b], self.xe[:2 * b, :self.W], W1, False, True, bias=P["model.0.bias"])
-            ops.interp_hidden(h0, b, interp, emb if self.have_labels else None,
+            ops.interp_hidden(h0, b, interp, self.emb[:2 * b] if self.have_labels else None,
                               W1[:, Gd:self.W] if self.have_labels else None)
+        elif self.gp_layout:        # the interpolates' first layer multiplied out, as the reference does
+            ops.gemm(h0[:2 * b], self.xe[:2 * b, :self.W], W1, False, True, bias=P["model.0.bias"])
+            ops.gemm(h0[2 * b:], self.xe[3 * b:4 * b, :self.W], W1, False, True, bias=P["model.0.bias"])
         else:
             ops.gemm(h0[off:], self.xe[:Rx, :self.W], W1, False, True, bias=P["model.0.bias"])
         for k in range(S - nx):
@@ -715,7 +729,8 @@ class CriticStack:
 
     def backward_params(self, b, scales):
         """Critic step: parameter gradients of  sum_s scales[s] * sum(validity of segment s)  over the first
-        len(scales) segments (needs nx == nseg), accumulated into the gradient arena."""
+        len(scales) segments (needs nx == nseg), accumulated into the gradient arena - except the first layer's
+        weight, which w1_grad() computes together with the penalty's terms from the dh0 this leaves behind."""
         ops, P, G, Gd = self.ops, self.net.P, self.net.G, self.Gd
         assert self.nx == self.S
         ns = len(scales)
@@ -740,11 +755,29 @@ class CriticStack:
         dh0 = self.g1024b[:R]
         ops.bn_bwd_seg(dh0, da1, self.h0[:R], None, self.pm1[:R], ns, self.stats[0], self.stats[1], P["model.1.weight"],
                        G["model.1.weight"], G["model.1.bias"], True, 0.2)
-        gW1 = G["model.0.weight"]
-        ops.gemm(gW1, dh0, self.xe[:R, :self.W], True, False, accumulate=True)
+        assert self.gp_layout and ns == 2
         if self.have_labels:
             ops.gemm(self.demb[:R], dh0, W1[:, Gd:], False, False)
             _embed_scatter(ops, G, self.demb[:R], self.lab[:R], True)
+
+    def w1_grad(self, b):
+        """The critic step's whole gradient of the first layer's weight (a third of the step's products) as one
+        product over three row blocks.  Its terms are dh0_r^T x_r + dh0_f^T x_f (Wasserstein chain), vh0^T x_i and
+        u0^T V (penalty chain).  The interpolates are x_i = a x_r + (1 - a) x_f row by row (GAN_functions.py:196),
+        so vh0^T x_i = (a vh0)^T x_r + ((1 - a) vh0)^T x_f: cg_gp_combine adds those multiples of vh0 to dh0 in place
+        and  dW1 = [dh0_r + a vh0; dh0_f + (1 - a) vh0; u0]^T [x_r; x_f; V]  - the adjacent row blocks of the two
+        workspaces.  The embedding columns of the interpolates are the generated batch's, not interpolated: there
+        the product misses (a vh0)^T (emb_f - emb_r), added by a second, 12-column product.  Call after
+        backward_params() and gp_backward() of the same step; written (first touch) to the gradient arena."""
+        ops, G, Gd = self.ops, self.net.G, self.Gd
+        assert self.gp_layout and self.alpha is not None
+        av, de = self.h1024a[:b], self.demb_diff[:b]
+        labels = self.have_labels and self.E > 0
+        ops.gp_combine(self.g1024b[:2 * b], self.g1024b[3 * b:4 * b], self.alpha, av,
+                       self.emb[:2 * b] if labels else None, de if labels else None)
+        ops.gemm(G["model.0.weight"], self.g1024b[:3 * b], self.xe[:3 * b, :self.W], True, False)
+        if labels:
+            ops.gemm(G["model.0.weight"][:, Gd:self.W], av, de, True, False, accumulate=True)
 
     def backward_input(self, b, coef, idx, scale, dfeat, dx_out):
         """Generator step (nx = nseg - 1): gradient w.r.t. the first input batch of
@@ -772,29 +805,24 @@ class CriticStack:
     def gp_backward(self, b, seg, lambda_gp, red, slot):
         """Segment `seg` (the last one) holds the forward on the interpolates: first-order chain to the input
         gradient, the penalty (row terms reduced into `slot`), and the second-order chain accumulating
-        d(lambda*penalty)/d(params)  (GAN_functions.py:194-204, :336-339).  The parameter gradients go to the
-        network's second gradient buffer, each tensor overwritten on first touch (the tensors this chain never
-        touches - biases - stay zero there), so the chain can run beside backward_params.
-
-        The first layer's weight gradient has two terms, vh0^T x_interp and u0^T V (V = d(penalty)/d(input gradient),
-        zeros under the embedding columns).  They are one product with twice the reduction length: vh0 and u0 are
-        written into adjacent row blocks of the hidden-gradient workspace, [vh0; u0], and V into the row block of the
-        stacked input that follows the interpolates, [x_interp; V] - one launch and one pass over the 20 MB gradient
-        instead of a product that writes it and a second one that reads, adds and writes it."""
-        ops, P, G, Gd = self.ops, self.net.P, self.net.G2, self.Gd
-        assert seg == self.S - 1 == self.nx - 1
-        sl, nxt = slice(seg * b, (seg + 1) * b), slice((seg + 1) * b, (seg + 2) * b)
+        d(lambda*penalty)/d(params) into the gradient arena (GAN_functions.py:194-204, :336-339) - except the first
+        layer's weight: its two terms here, vh0^T x_interp and u0^T V (V = d(penalty)/d(input gradient), zeros under
+        the embedding columns), are left to w1_grad(), for which u0, vh0 and V are written into the row blocks
+        named in the class docstring."""
+        ops, P, G, Gd = self.ops, self.net.P, self.net.G, self.Gd
+        assert self.gp_layout and seg == 2
+        sl = slice(2 * b, 3 * b)
         mean, invstd = self.stats[0][seg], self.stats[1][seg]
         h0, pm1, pm2, pm3 = self.h0[sl], self.pm1[sl], self.pm2[sl], self.pm3[sl]
         W1, W2, W3, w4 = P["model.0.weight"], P["model.4.weight"], P["model.7.weight"], P["model.9.weight"]
         u3, u2, u1 = self.g256[sl], self.g512[sl], self.g1024a[sl]
-        vh0, u0 = self.g1024b[sl], self.g1024b[nxt]
-        ux = self.xe[nxt, :Gd]
+        u0, vh0 = self.g1024b[2 * b:3 * b], self.g1024b[3 * b:4 * b]
+        ux = self.xe[2 * b:3 * b, :Gd]
         if self.E:      # V is zero under the embedding columns; a batch of another size leaves other rows' values there
             if hasattr(ops, "copy"):
-                ops.copy(self.xe[nxt, Gd:self.W], self.zero_emb[:b])
+                ops.copy(self.xe[2 * b:3 * b, Gd:self.W], self.zero_emb[:b])
             else:
-                self.xe[nxt, Gd:self.W].zero_()
+                self.xe[2 * b:3 * b, Gd:self.W].zero_()
         ops.gemm(u3, self.ones[:b], w4, False, False, epi=EPI_MUL, E=pm3)
         ops.gemm(u2, u3, W3, False, False, epi=EPI_MUL, E=pm2)
         ops.gemm(u1, u2, W2, False, False, epi=EPI_MUL, E=pm1)
@@ -806,22 +834,20 @@ class CriticStack:
         w = self.h1024a[:b]
         ops.gemm(w, ux, W1[:, :Gd], False, True)
         vu1 = self.h1024b[:b]
-        ops.bn_bwd_bwd(vu1, vh0, G["model.1.weight"], False, w, u1, h0, mean, invstd, P["model.1.weight"], self.ubar,
+        ops.bn_bwd_bwd(vu1, vh0, G["model.1.weight"], True, w, u1, h0, mean, invstd, P["model.1.weight"], self.ubar,
                        self.mbar)
-        ops.gemm(G["model.0.weight"], self.g1024b[seg * b:(seg + 2) * b], self.xe[seg * b:(seg + 2) * b, :self.W],
-                 True, False)               # first touch: all columns
         t1 = vu1
         ops.mul(t1, vu1, pm1)
-        ops.gemm(G["model.4.weight"], u2, t1, True, False)
+        ops.gemm(G["model.4.weight"], u2, t1, True, False, accumulate=True)
         t2 = self.h512[:b]
         ops.gemm(t2, t1, W2, False, True, epi=EPI_MUL, E=pm2)
-        ops.gemm(G["model.7.weight"], u3, t2, True, False)
+        ops.gemm(G["model.7.weight"], u3, t2, True, False, accumulate=True)
         vu3 = self.h256[:b]
         ops.gemm(vu3, t2, W3, False, True, epi=EPI_MUL, E=pm3)
-        ops.colsum(G["model.9.weight"], vu3, 1.0, False)
+        ops.colsum(G["model.9.weight"], vu3, 1.0, True)
         if self.have_labels:
             ops.gemm(self.demb2[:b], vh0, W1[:, Gd:], False, False)
-            _embed_scatter(ops, G, self.demb2[:b], self.lab[sl], False)
+            _embed_scatter(ops, G, self.demb2[:b], self.lab[sl], True)
 
 
 class EngineBase:
@@ -1004,8 +1030,7 @@ class StepEngine(EngineBase):
         split = {n: split_state(sd) for n, sd in nets.items()}
         order = {n: _arena_order(list(split[n][0].keys())) for n in nets}
         self.arena_g = Arena(ops, [((n, k), tuple(split[n][0][k].shape)) for n in ("g_m2h", "g_h2m") for k in order[n]])
-        self.arena_d = Arena(ops, [((n, k), tuple(split[n][0][k].shape)) for n in ("d_m", "d_h") for k in order[n]],
-                             second_grad=True)
+        self.arena_d = Arena(ops, [((n, k), tuple(split[n][0][k].shape)) for n in ("d_m", "d_h") for k in order[n]])
         self.nets = {}
         for n in ("g_m2h", "g_h2m", "d_m", "d_h"):
             arena = self.arena_g if n.startswith("g_") else self.arena_d
@@ -1186,26 +1211,28 @@ class StepEngine(EngineBase):
             m1, m2, alpha = drawn[name] if drawn else self._critic_noise(noise, b, 3, alpha_before=2)
             # real | generated | interpolated batch and their labels into the stacked input, one launch
             ds.have_labels = real_lab is not None
-            ops.critic_inputs(ds.x[:3 * b], ds.lab[:3 * b] if ds.have_labels else None, real, fake, alpha,
+            ops.critic_inputs(ds.x[:4 * b], ds.lab[:3 * b] if ds.have_labels else None, real, fake, alpha,
                               real_lab.contiguous() if ds.have_labels else None,
-                              fake_lab.contiguous() if ds.have_labels else None)
+                              fake_lab.contiguous() if ds.have_labels else None, interp_block=3)
+            ds.alpha = alpha
             val, _ = ds.forward(b, m1, m2, (0, 1, 2), interp=alpha if self.interp_by_linearity else None)
             ops.reduce_sum(self.red, s0, val[:b])
             ops.reduce_sum(self.red, s0 + 1, val[b:2 * b])
         self._many(lambda: critic_fwd("d_m", mouse, mouse_cat, fake_mouse, human_cat, S_DM_REAL),
                    lambda: critic_fwd("d_h", human, human_cat, fake_human, mouse_cat, S_DH_REAL))
-        # per critic two independent backward chains: Wasserstein terms (real, generated) into the gradient
-        # arena, penalty (double backward on the interpolates) into the second gradient buffer.  (Measured: one
-        # branch per critic - forward, then both chains one after the other - takes the same time, 2.98 ms per
-        # iteration either way: the step is bound by what its kernels take, not by how many run side by side.)
-        def wasserstein(name):      # each critic's gradients are cleared in the branch that accumulates into them
+        # One backward branch per critic: its gradients cleared, the penalty's double-backward chain on the
+        # interpolates, the Wasserstein chain on the real and the generated rows, then the first layer's weight
+        # gradient from what both left behind (CriticStack.w1_grad).  Every tensor is accumulated by one stream, so
+        # there is no second gradient buffer and nothing to add afterwards.  (Four branches - the two chains of a
+        # critic side by side - measured the same with the chains' own first-layer products, 2.887 against 2.904 ms;
+        # with one product for both chains they must meet anyway.)
+        def backward(name, slot):
+            ds = self.dstack[name]
             self.arena_d.net_grad(name).zero_()
-            self.dstack[name].backward_params(b, (-1.0 / b, 1.0 / b))
-        self._many(lambda: wasserstein("d_m"),
-                   lambda: self.dstack["d_m"].gp_backward(b, 2, cfg["lambda_gp"], self.red, S_DM_REAL + 2),
-                   lambda: wasserstein("d_h"),
-                   lambda: self.dstack["d_h"].gp_backward(b, 2, cfg["lambda_gp"], self.red, S_DH_REAL + 2))
-        self.arena_d.g.add_(self.arena_d.g2)
+            ds.gp_backward(b, 2, cfg["lambda_gp"], self.red, slot)
+            ds.backward_params(b, (-1.0 / b, 1.0 / b))
+            ds.w1_grad(b)
+        self._many(lambda: backward("d_m", S_DM_REAL + 2), lambda: backward("d_h", S_DH_REAL + 2))
         ops.sum_parts(self.d_tot, self.red, self.d_slots, self.d_scales)
 
     _d_noise = None      # masks and alpha of the critic step drawn before its critics' part is issued

@@ -426,10 +426,11 @@ class HipOps:
                                    G, self._stream())
         _lib.check(st, "cg_gp_interp")
 
-    def critic_inputs(self, out, lab_out, real, fake, alpha, real_lab, fake_lab):
-        """out (3M, G) <- [real; fake; interpolates], lab_out (3M, n_cov) <- [real_lab; fake_lab; fake_lab]."""
+    def critic_inputs(self, out, lab_out, real, fake, alpha, real_lab, fake_lab, interp_block=2):
+        """out <- [real; fake; (interp_block - 2 row blocks left alone); interpolates],
+        lab_out (3M, n_cov) <- [real_lab; fake_lab; fake_lab]."""
         M, G = real.shape
-        assert out.shape == (3 * M, G) and fake.shape == (M, G) and alpha.numel() == M
+        assert out.shape == ((interp_block + 1) * M, G) and fake.shape == (M, G) and alpha.numel() == M
         n_cov = 0
         if lab_out is not None:
             n_cov = real_lab.shape[1]
@@ -437,8 +438,8 @@ class HipOps:
             assert lab_out.shape == (3 * M, n_cov) and real_lab.shape == (M, n_cov) and fake_lab.shape == (M, n_cov)
             assert lab_out.is_contiguous() and real_lab.is_contiguous() and fake_lab.is_contiguous()
         st = self.lib.cg_critic_inputs(_ptr(out), _ld(out), _ptr(real), _ld(real), _ptr(fake), _ld(fake), _ptr(alpha), M,
-                                       G, _ptr(lab_out), _ptr(real_lab), _ptr(fake_lab), n_cov, self._twin(out)[0],
-                                       self._stream())
+                                       G, _ptr(lab_out), _ptr(real_lab), _ptr(fake_lab), n_cov, int(interp_block),
+                                       self._twin(out)[0], self._stream())
         _lib.check(st, "cg_critic_inputs")
 
     def interp_hidden(self, H, M, alpha, emb, We):
@@ -453,6 +454,19 @@ class HipOps:
         st = self.lib.cg_interp_hidden(_ptr(H), _ld(H), _ptr(alpha), _ptr(emb), _ld(emb), E, _ptr(We), _ld(We), M, N,
                                        self._stream())
         _lib.check(st, "cg_interp_hidden")
+
+    def gp_combine(self, D, VH, alpha, AV, emb, dE):
+        """D[:M] += alpha VH, D[M:] += (1 - alpha) VH (in place), AV <- alpha VH, dE <- emb[M:] - emb[:M] (emb, dE may
+        be None): see cg_gp_combine."""
+        M, N = VH.shape
+        assert D.shape == (2 * M, N) and AV.shape == (M, N) and alpha.numel() == M
+        E = 0
+        if emb is not None:
+            E = emb.shape[1]
+            assert emb.shape[0] >= 2 * M and tuple(dE.shape) == (M, E) and emb.stride(1) == 1 and dE.stride(1) == 1
+        st = self.lib.cg_gp_combine(_ptr(D), _ld(D), _ptr(VH), _ld(VH), _ptr(alpha), _ptr(AV), _ld(AV), _ptr(emb),
+                                    _ld(emb), E, _ptr(dE), _ld(dE), M, N, self._twin(D)[0], self._stream())
+        _lib.check(st, "cg_gp_combine")
 
     def gp_penalty(self, V, rowpen, UX, lambda_gp):
         M, G = UX.shape

@@ -274,11 +274,13 @@ int cg_gp_interp(float* out, int ldo, const float* real, int ldr, const float* f
  * The three input batches of a critic step in one pass (:326-336): rows [0, M) of `out` <- real, [M, 2M) <- fake,
  * [2M, 3M) <- alpha*real + (1-alpha)*fake; lab_out (3M x n_cov int64, may be NULL) <- real_lab, fake_lab, fake_lab
  * (the critic sees the generated and the interpolated batch with the labels of the generated one, :328-329).
+ * interp_block (>= 2): the interpolates go to rows [interp_block M, (interp_block + 1) M) instead of [2M, 3M) - a
+ * caller may keep another row block between the generated batch and the interpolates (cg_gp_combine's caller does).
  * out_bf16 (may be NULL): bf16 image of `out`, same leading dimension.
  */
 int cg_critic_inputs(float* out, int ldo, const float* real, int ldr, const float* fake, int ldf,
                      const float* alpha, int M, int G, int64_t* lab_out, const int64_t* real_lab,
-                     const int64_t* fake_lab, int n_cov, void* out_bf16, void* stream);
+                     const int64_t* fake_lab, int n_cov, int interp_block, void* out_bf16, void* stream);
 /*
  * The critic's first Linear (GAN_functions.py:165, on [x | emb], :184) applied to the interpolated batch of the
  * gradient penalty (:196-199) without a product.  The layer is linear and the interpolates are
@@ -290,6 +292,21 @@ int cg_critic_inputs(float* out, int ldo, const float* real, int ldr, const floa
  */
 int cg_interp_hidden(float* H, int ldh, const float* alpha, const float* emb, int lde, int E,
                      const float* We, int ldw, int M, int N, void* stream);
+
+/*
+ * The penalty's first-layer weight-gradient term folded into the Wasserstein terms (:326-339 with :196-199).  The
+ * interpolates are x_i = a x_r + (1 - a) x_f row by row, so with vh0 the second-order chain's gradient at the first
+ * layer's output on the interpolates,  vh0^T x_i = (a vh0)^T x_r + ((1 - a) vh0)^T x_f:  the critic step's whole
+ * gradient of the first layer's weight is  (dh0_r + a vh0)^T x_r + (dh0_f + (1 - a) vh0)^T x_f + u0^T V,  three row
+ * blocks instead of four - one product the size of the first layer less per critic and step.  In place on D
+ * (2M x N: dh0 of the real rows, then of the generated rows):  D[m] += a_m VH[m],  D[M + m] += (1 - a_m) VH[m].
+ * The embedding columns of the interpolates are those of the generated batch, not interpolated; the product over
+ * [x | emb] with the combined rows therefore misses  (a vh0)^T (emb_f - emb_r)  there: AV (M x N) receives a vh0 and
+ * dE (M x E, emb = rows of embeddings of the real then the generated batch, may be NULL) receives emb_f - emb_r for
+ * that correction product.  d_bf16 (may be NULL): bf16 image of D.
+ */
+int cg_gp_combine(float* D, int ldd, const float* VH, int ldv, const float* alpha, float* AV, int ldav,
+                  const float* emb, int lde, int E, float* dE, int ldde, int M, int N, void* d_bf16, void* stream);
 
 /*
  * Row norms and the penalty (:203): n_m = ||UX[m,:]||_2; rowpen[m] = (n_m-1)^2

@@ -274,12 +274,12 @@ class CpuOps:
         a = alpha.reshape(-1, 1)
         out.copy_(a * real + (1 - a) * fake)
 
-    def critic_inputs(self, out, lab_out, real, fake, alpha, real_lab, fake_lab):
+    def critic_inputs(self, out, lab_out, real, fake, alpha, real_lab, fake_lab, interp_block=2):
         M = real.shape[0]
         a = alpha.reshape(-1, 1)
         out[:M].copy_(real)
         out[M:2 * M].copy_(fake)
-        out[2 * M:].copy_(a * real + (1 - a) * fake)
+        out[interp_block * M:(interp_block + 1) * M].copy_(a * real + (1 - a) * fake)
         if lab_out is not None:
             lab_out[:M].copy_(real_lab)
             lab_out[M:2 * M].copy_(fake_lab)
@@ -291,6 +291,17 @@ class CpuOps:
         if emb is not None:
             v = v + a * ((emb[M:2 * M] - emb[:M]) @ We.t())
         H[2 * M:3 * M].copy_(v)
+
+    def gp_combine(self, D, VH, alpha, AV, emb, dE):
+        """cg_gp_combine: D[:M] += a VH, D[M:] += (1 - a) VH, AV <- a VH, dE <- emb[M:2M] - emb[:M]."""
+        M = VH.shape[0]
+        a = alpha.reshape(-1, 1).to(VH.dtype)
+        av = a * VH
+        D[:M].add_(av)
+        D[M:2 * M].add_(VH - av)
+        AV.copy_(av)
+        if emb is not None:
+            dE.copy_(emb[M:2 * M] - emb[:M])
 
     def gp_penalty(self, V, rowpen, UX, lambda_gp):
         M = UX.shape[0]
