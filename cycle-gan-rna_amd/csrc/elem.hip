@@ -164,7 +164,8 @@ __global__ void gp_interp_kernel(float* out, int ldo, const float* real, int ldr
 }
 
 // The critic step's three input batches in one pass: rows [0, M) of `out` <- real, [M, 2M) <- fake, [2M, 3M) <- the
-// interpolates; and their labels (n_cov int64 per row): real's, fake's, fake's.
+// interpolates (row block ib instead of 2 on request); and their labels (n_cov int64 per row): real's, fake's, -1 for
+// row blocks in between, fake's.
 __global__ void critic_inputs_kernel(float* out, int ldo, const float* real, int ldr, const float* fake, int ldf,
                                      const float* alpha, int M, int G, int64_t* lab_out, const int64_t* real_lab,
                                      const int64_t* fake_lab, int n_cov, u16* out16, int ib) {
@@ -185,7 +186,8 @@ __global__ void critic_inputs_kernel(float* out, int ldo, const float* real, int
     for (int i = t; i < M * n_cov; i += nt) {
       lab_out[i] = real_lab[i];
       lab_out[M * n_cov + i] = fake_lab[i];
-      lab_out[2 * M * n_cov + i] = fake_lab[i];
+      for (int k = 2; k < ib; ++k) lab_out[(size_t)k * M * n_cov + i] = -1;      // row blocks that hold no cells
+      lab_out[(size_t)ib * M * n_cov + i] = fake_lab[i];
     }
   }
 }

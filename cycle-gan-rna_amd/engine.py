@@ -650,7 +650,7 @@ class CriticStack:
         self.xe = Zs((nx + 1) * B, _pad4(self.W))
         self.x = self.xe[:, :in_dim]
         self.emb = self.xe[:, in_dim:self.W]
-        self.lab = ops.to_device(torch.zeros(nx * B, getattr(engine, "n_cov", 1), dtype=torch.int64))
+        self.lab = ops.to_device(torch.zeros((nx + 1) * B, getattr(engine, "n_cov", 1), dtype=torch.int64))
         self.h0, self.a1, self.pm1 = Z(S * B, 1024), Zs(S * B, 1024), Z(S * B, 1024)
         self.stats = (Z(S, 1024), Z(S, 1024))
         self.a2, self.pm2 = Zs(S * B, 512), Z(S * B, 512)
@@ -661,8 +661,7 @@ class CriticStack:
         self.g256, self.g512, self.g1024a, self.g1024b = Z(S * B, 256), Zs(S * B, 512), Z(S * B, 1024), Zs((S + 1) * B, 1024)
         self.h256, self.h512, self.h1024a, self.h1024b = Z(B, 256), Zs(B, 512), Z(B, 1024), Z(B, 1024)
         self.dsum = Z(B, 1024)
-        self.demb = Z(nx * B, self.E)
-        self.demb2 = Z(B, self.E)
+        self.demb = Z((nx + 1) * B, self.E)
         self.zero_emb = Z(B, max(self.E, 1))
         self.demb_diff = Z(B, max(self.E, 1))
         self.alpha = None                       # the interpolation weights of the current critic step (forward)
@@ -698,10 +697,10 @@ class CriticStack:
         if interp is not None:
             self.alpha = interp
         # row blocks of the stacked input that hold input batches: 0, 1 and - in the critic step's layout - 3
-        blocks = [(0, 2 * b, 0), (3 * b, 4 * b, 2 * b)] if self.gp_layout else [(0, Rx, 0)]
-        for lo, hi, lab0 in blocks:
+        blocks = [(0, 2 * b), (3 * b, 4 * b)] if self.gp_layout else [(0, Rx)]
+        for lo, hi in blocks:
             if self.have_labels:
-                _embed_gather(ops, self.emb[lo:hi], P, self.lab[lab0:lab0 + hi - lo])
+                _embed_gather(ops, self.emb[lo:hi], P, self.lab[lo:hi])
             else:
                 self.emb[lo:hi].zero_()
         h0 = self.h0[:R]
@@ -755,10 +754,7 @@ class CriticStack:
         dh0 = self.g1024b[:R]
         ops.bn_bwd_seg(dh0, da1, self.h0[:R], None, self.pm1[:R], ns, self.stats[0], self.stats[1], P["model.1.weight"],
                        G["model.1.weight"], G["model.1.bias"], True, 0.2)
-        assert self.gp_layout and ns == 2
-        if self.have_labels:
-            ops.gemm(self.demb[:R], dh0, W1[:, Gd:], False, False)
-            _embed_scatter(ops, G, self.demb[:R], self.lab[:R], True)
+        assert self.gp_layout and ns == 2       # the embedding tables' gradient: w1_grad()
 
     def w1_grad(self, b):
         """The critic step's whole gradient of the first layer's weight (a third of the step's products) as one
@@ -773,6 +769,12 @@ class CriticStack:
         assert self.gp_layout and self.alpha is not None
         av, de = self.h1024a[:b], self.demb_diff[:b]
         labels = self.have_labels and self.E > 0
+        if labels:
+            # the embedding tables' gradient of both chains in one product and one scatter over all four row blocks:
+            # [dh0_r; dh0_f; u0; vh0] W1[:, G:] summed per cell type - the rows of u0 carry the label -1 (no cell) and
+            # drop out
+            ops.gemm(self.demb[:4 * b], self.g1024b[:4 * b], self.net.P["model.0.weight"][:, Gd:], False, False)
+            _embed_scatter(ops, G, self.demb[:4 * b], self.lab[:4 * b], True)
         ops.gp_combine(self.g1024b[:2 * b], self.g1024b[3 * b:4 * b], self.alpha, av,
                        self.emb[:2 * b] if labels else None, de if labels else None)
         ops.gemm(G["model.0.weight"], self.g1024b[:3 * b], self.xe[:3 * b, :self.W], True, False)
@@ -845,9 +847,6 @@ class CriticStack:
         vu3 = self.h256[:b]
         ops.gemm(vu3, t2, W3, False, True, epi=EPI_MUL, E=pm3)
         ops.colsum(G["model.9.weight"], vu3, 1.0, True)
-        if self.have_labels:
-            ops.gemm(self.demb2[:b], vh0, W1[:, Gd:], False, False)
-            _embed_scatter(ops, G, self.demb2[:b], self.lab[sl], True)
 
 
 class EngineBase:
@@ -1211,7 +1210,7 @@ class StepEngine(EngineBase):
             m1, m2, alpha = drawn[name] if drawn else self._critic_noise(noise, b, 3, alpha_before=2)
             # real | generated | interpolated batch and their labels into the stacked input, one launch
             ds.have_labels = real_lab is not None
-            ops.critic_inputs(ds.x[:4 * b], ds.lab[:3 * b] if ds.have_labels else None, real, fake, alpha,
+            ops.critic_inputs(ds.x[:4 * b], ds.lab[:4 * b] if ds.have_labels else None, real, fake, alpha,
                               real_lab.contiguous() if ds.have_labels else None,
                               fake_lab.contiguous() if ds.have_labels else None, interp_block=3)
             ds.alpha = alpha

@@ -428,14 +428,15 @@ class HipOps:
 
     def critic_inputs(self, out, lab_out, real, fake, alpha, real_lab, fake_lab, interp_block=2):
         """out <- [real; fake; (interp_block - 2 row blocks left alone); interpolates],
-        lab_out (3M, n_cov) <- [real_lab; fake_lab; fake_lab]."""
+        lab_out, the same row blocks <- [real_lab; fake_lab; (-1 ...); fake_lab]."""
         M, G = real.shape
         assert out.shape == ((interp_block + 1) * M, G) and fake.shape == (M, G) and alpha.numel() == M
         n_cov = 0
         if lab_out is not None:
             n_cov = real_lab.shape[1]
             _chk(lab_out, torch.int64), _chk(real_lab, torch.int64), _chk(fake_lab, torch.int64)
-            assert lab_out.shape == (3 * M, n_cov) and real_lab.shape == (M, n_cov) and fake_lab.shape == (M, n_cov)
+            assert lab_out.shape == ((interp_block + 1) * M, n_cov) and real_lab.shape == (M, n_cov) and \
+                fake_lab.shape == (M, n_cov)
             assert lab_out.is_contiguous() and real_lab.is_contiguous() and fake_lab.is_contiguous()
         st = self.lib.cg_critic_inputs(_ptr(out), _ld(out), _ptr(real), _ld(real), _ptr(fake), _ld(fake), _ptr(alpha), M,
                                        G, _ptr(lab_out), _ptr(real_lab), _ptr(fake_lab), n_cov, int(interp_block),

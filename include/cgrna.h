@@ -275,7 +275,9 @@ int cg_gp_interp(float* out, int ldo, const float* real, int ldr, const float* f
  * [2M, 3M) <- alpha*real + (1-alpha)*fake; lab_out (3M x n_cov int64, may be NULL) <- real_lab, fake_lab, fake_lab
  * (the critic sees the generated and the interpolated batch with the labels of the generated one, :328-329).
  * interp_block (>= 2): the interpolates go to rows [interp_block M, (interp_block + 1) M) instead of [2M, 3M) - a
- * caller may keep another row block between the generated batch and the interpolates (cg_gp_combine's caller does).
+ * caller may keep another row block between the generated batch and the interpolates (cg_gp_combine's caller does);
+ * lab_out then has (interp_block + 1) M rows too, the rows of blocks in between set to -1 (no cell: cg_embed_scatter
+ * skips such rows).
  * out_bf16 (may be NULL): bf16 image of `out`, same leading dimension.
  */
 int cg_critic_inputs(float* out, int ldo, const float* real, int ldr, const float* fake, int ldf,

@@ -244,7 +244,8 @@ class CpuOps:
     def embed_scatter(self, dtable, dout, labels, accumulate):
         lab = labels.reshape(labels.shape[0], -1)[:, 0]
         acc = torch.zeros_like(dtable)
-        acc.index_add_(0, lab, dout.contiguous())
+        keep = lab >= 0                      # a negative label marks a row that belongs to no cell
+        acc.index_add_(0, lab[keep], dout.contiguous()[keep])
         dtable.copy_(dtable + acc if accumulate else acc)
 
     def reparam_fwd(self, z, ml, eps):
@@ -283,7 +284,8 @@ class CpuOps:
         if lab_out is not None:
             lab_out[:M].copy_(real_lab)
             lab_out[M:2 * M].copy_(fake_lab)
-            lab_out[2 * M:].copy_(fake_lab)
+            lab_out[2 * M:interp_block * M].fill_(-1)
+            lab_out[interp_block * M:(interp_block + 1) * M].copy_(fake_lab)
 
     def interp_hidden(self, H, M, alpha, emb, We):
         a = alpha.reshape(-1, 1)
