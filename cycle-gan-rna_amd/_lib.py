@@ -46,6 +46,7 @@ SIGNATURES = {
     "cg_tok_bwd_mid": ([P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, P], I),
     "cg_tok_bwd_in": ([P, P, P, P, P, P, P, P, P, P, P, P, P, I, P], I),
     "cg_tok_wgrad_reduce": ([P, P, P, P, I, P], I),
+    "cg_bn_running_update": ([P, P, P, P, I, I, F, F, P], I),
     "cg_bn_eval": ([P, I, P, I, I, I, P, P, P, P, F, F, P, I, P], I),
     "cg_bn_bwd": ([P, I, P, I, P, I, P, I, P, I, P, P, P, P, P, I, P, P, F, I, I, P, I, P, Z, P], I),
     "cg_bn_bwd_bwd": ([P, I, P, I, P, I, P, I, P, I, P, I, P, P, P, P, P, I, I, P, P, Z, P], I),

@@ -177,6 +177,20 @@ __global__ void __launch_bounds__(256) bn_eval_kernel(float* Y, int ldy, const f
   }
 }
 
+// One more update of the running statistics with batch statistics that a forward pass has stored (mean, invstd).
+__global__ void __launch_bounds__(256) bn_running_update_kernel(float* rmean, float* rvar, const float* mean,
+                                                               const float* invstd, int N, int M, float eps,
+                                                               float momentum) {
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= N) return;
+  const double is = invstd[col];
+  double var_d = 1.0 / (is * is) - (double)eps;
+  if (var_d < 0.0) var_d = 0.0;
+  rmean[col] = (1.f - momentum) * rmean[col] + momentum * mean[col];
+  const float unb = (float)(var_d * ((double)M / (double)(M > 1 ? M - 1 : 1)));
+  rvar[col] = (1.f - momentum) * rvar[col] + momentum * unb;
+}
+
 // ---------------- backward ----------------
 __global__ void __launch_bounds__(256) bn_bwd_stats(double* ws, const float* dY, int lddy, const float* X, int ldx,
                                                     const float* Y, int ldy, const float* PM, int ldpm,
@@ -532,6 +546,14 @@ extern "C" int cg_bn_fwd_static(float* Y, int ldy, const float* X, int ldx, int 
   // every partial sum the second launch reads is written by the first, so nothing in the array has to start at zero
   return cg_bn_fwd_seg(Y, ldy, X, ldx, M, 1, 0u, N, gamma, beta, eps, mean_out, invstd_out, running_mean, running_var,
                        momentum, slope, mask, ldmask, pm_out, ldpm, ybf16, ldybf16, ws, BN_STATIC_BYTES, stream);
+}
+
+extern "C" int cg_bn_running_update(float* running_mean, float* running_var, const float* mean, const float* invstd,
+                                    int M, int N, float eps, float momentum, void* stream) {
+  if (!running_mean || !running_var || !mean || !invstd || M <= 0 || N <= 0) return CG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(bn_running_update_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, running_mean,
+                     running_var, mean, invstd, N, M, eps, momentum);
+  return cg_launch_status();
 }
 
 extern "C" int cg_bn_eval(float* Y, int ldy, const float* X, int ldx, int M, int N, const float* gamma,

@@ -258,6 +258,7 @@ class GenPass:
         if getattr(ops, "precision", "fp32") == "bf16" and hasattr(ops, "image_of"):
             self.x16 = ops.zeros(B * _pad4(in_dim), dtype=torch.bfloat16)
         self.x_img = None
+        self._own_encoder = (self.enc_h0, self.enc_a, self.enc_stats, self.ml)
         # [mu; log_var] as one matrix (see _arena_order)
         ar, hl = net.arena, H[-1]
         self.W_ml = ar.flat(ar.p, (net.name, "mu.weight"), 2 * L * hl).view(2 * L, hl)
@@ -293,22 +294,43 @@ class GenPass:
         else:
             ops.bn_eval(out_a, out_h0, gamma, beta, rm, rv, 0.0)
 
-    def forward(self, x, labels, noise, train=True):
+    def forward(self, x, labels, noise, train=True, encoder_of=None):
+        """encoder_of: a pass of the SAME network (this one included) whose last train-mode forward saw the same
+        batch with the same weights - the critic step's call of the generator, when the generator step of the same
+        iteration calls it again (GAN_functions.py:326-327, :344-345; only the critics change in between).  The
+        encoder and the two heads are deterministic, so their activations, pre-activations and batch statistics are
+        taken over from that pass (its buffers become this pass's, for the backward pass too) instead of being
+        computed again; what the second call would do to the running statistics of the encoder's BatchNorm layers
+        is applied from the stored batch statistics.  Everything after the heads draws its own noise as usual."""
         ops, P, L = self.ops, self.net.P, self.L
         b = x.shape[0]
-        self.b, self.x, self.labels, self.train = b, x, labels, train
         nh = len(self.hidden)
-        a = x
-        self.x_img = None
-        if self.x16 is not None and x.dim() == 2 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.stride(0) <= _pad4(self.in_dim):
-            self.x_img = ops.image_of(x, self.x16)
-        for li in range(nh):
-            self._linear_bn_relu(self.enc_a[li][:b], self.enc_h0[li][:b], self.enc_stats[li], a,
-                                 f"encoder.{3 * li}", f"encoder.{3 * li + 1}", train,
-                                 a16=self.x_img if li == 0 else None)
-            a = self.enc_a[li][:b]
-        ml = self.ml[:b]
-        ops.gemm(ml, a, self.W_ml, False, True, bias=self.b_ml)            # mu | log_var, :139
+        if encoder_of is not None:
+            src = encoder_of
+            assert train and src.train and src.b == b and src.net is self.net
+            self.enc_h0, self.enc_a, self.enc_stats, self.ml = src.enc_h0, src.enc_a, src.enc_stats, src.ml
+            self.b, self.x, self.labels, self.train, self.x_img = b, src.x, labels, train, src.x_img
+            for li in range(nh):
+                bn = f"encoder.{3 * li + 1}"
+                _, _, rm, rv = self._bn(bn)
+                ops.bn_running_update(rm, rv, self.enc_stats[li][0], self.enc_stats[li][1], b)
+                self.net.nbt[bn + ".num_batches_tracked"] += 1
+            ml = self.ml[:b]
+        else:
+            self.enc_h0, self.enc_a, self.enc_stats, self.ml = self._own_encoder
+            self.b, self.x, self.labels, self.train = b, x, labels, train
+            a = x
+            self.x_img = None
+            if self.x16 is not None and x.dim() == 2 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and \
+                    x.stride(0) <= _pad4(self.in_dim):
+                self.x_img = ops.image_of(x, self.x16)
+            for li in range(nh):
+                self._linear_bn_relu(self.enc_a[li][:b], self.enc_h0[li][:b], self.enc_stats[li], a,
+                                     f"encoder.{3 * li}", f"encoder.{3 * li + 1}", train,
+                                     a16=self.x_img if li == 0 else None)
+                a = self.enc_a[li][:b]
+            ml = self.ml[:b]
+            ops.gemm(ml, a, self.W_ml, False, True, bias=self.b_ml)            # mu | log_var, :139
         self.eps = noise.randn((b, L))
         ops.reparam_fwd(self.z[0][:b], ml, self.eps)
         t = b * SEQ_LEN
@@ -1259,11 +1281,17 @@ class StepEngine(EngineBase):
                     gp_m=float(t[2]) / float(self.cfg["lambda_gp"]), gp_h=float(t[5]) / float(self.cfg["lambda_gp"]))
 
     # ---- generator step (:343-419) -------------------------------------------------------
+    # the passes whose encoder the generator step's first forward takes over (GenPass.forward, encoder_of): set by
+    # iteration() around a generator step that follows the critic step of the same batch
+    _g_encoder_of = None
+    reuse_encoder = not os.environ.get("CGRNA_NO_ENCODER_REUSE")
+
     def g_step(self, mouse, human, mouse_cat, human_cat, noise):
         b = mouse.shape[0]
         self._begin_opt(self.arena_g, self.lr_g)
         multi = self.sync.enabled and self._d_pending_lr is not None
-        self._run_parts("g", b, (mouse, human, mouse_cat, human_cat), noise,
+        # a captured generator step with the encoder taken over is a different graph from one that computes it
+        self._run_parts("g" if self._g_encoder_of is None else "ge", b, (mouse, human, mouse_cat, human_cat), noise,
                         [("graph", self._g_first),
                          ("eager", self._d_wait_pending if multi else None),      # the critics are needed from here on
                          ("graph", self._d_apply_pending if multi else None),
@@ -1288,9 +1316,11 @@ class StepEngine(EngineBase):
         # streams; the human-side member comes first, as in the reference, so a sequential run draws its noise in
         # the reference's order.
 
-        def fwd(key, p, x, lab):
-            o[key] = p.forward(x, lab, noise)
-        self._two(lambda: fwd("fh", A, mouse, mouse_cat), lambda: fwd("fm", Bp, human, human_cat))
+        src = self._g_encoder_of or {}
+
+        def fwd(key, p, x, lab, name):
+            o[key] = p.forward(x, lab, noise, encoder_of=src.get(name))
+        self._two(lambda: fwd("fh", A, mouse, mouse_cat, "g_m2h"), lambda: fwd("fm", Bp, human, human_cat, "g_h2m"))
         self._g_state = (mouse, human, mouse_cat, human_cat, o, noise)
 
     def _g_rest(self):
@@ -1490,7 +1520,12 @@ class StepEngine(EngineBase):
         else:
             self.d_step(mouse, human, mouse_cat, human_cat, noise)
             if i % self.cfg["nb_critic"] == 0:
-                self.g_step(mouse, human, mouse_cat, human_cat, noise)
+                # the critic step has just called both generators on this batch, in these workspaces
+                self._g_encoder_of = self.gen_a if self.reuse_encoder else None
+                try:
+                    self.g_step(mouse, human, mouse_cat, human_cat, noise)
+                finally:
+                    self._g_encoder_of = None
         out = {}
         if metrics and i % self.cfg["nb_critic"] == 0:
             if critic:
@@ -1602,10 +1637,12 @@ class StepEngine(EngineBase):
             for st in lanes:
                 self._after(st, main)
             passes = self.gen_a if mode == "g" else self.gen_d[1 - s]
+            # the generator step's first forward follows the critic step's forward of the same batch (set s)
+            src = self.gen_d[s] if (mode == "g" and self.reuse_encoder) else {}
             with self._Lane(self, noise, lanes[0]):
-                out_h = passes["g_m2h"].forward(mouse, mouse_cat, noise)
+                out_h = passes["g_m2h"].forward(mouse, mouse_cat, noise, encoder_of=src.get("g_m2h"))
             with self._Lane(self, noise, lanes[1]):
-                out_m = passes["g_h2m"].forward(human, human_cat, noise)
+                out_m = passes["g_h2m"].forward(human, human_cat, noise, encoder_of=src.get("g_h2m"))
             if mode == "g":
                 self._g_state = (mouse, human, mouse_cat, human_cat, dict(fh=out_h, fm=out_m), noise)
             else:

@@ -341,6 +341,14 @@ class HipOps:
                                  _ptr(rvar), eps, float(slope), *self._twin(Y), self._stream())
         _lib.check(st, "cg_bn_eval")
 
+    def bn_running_update(self, rmean, rvar, mean, invstd, M, eps=1e-5, momentum=0.1):
+        """The running-statistics update of one more train-mode call on the batch whose statistics bn_fwd stored."""
+        N = mean.numel()
+        assert rmean.numel() == N and rvar.numel() == N and invstd.numel() == N
+        st = self.lib.cg_bn_running_update(_ptr(rmean), _ptr(rvar), _ptr(mean), _ptr(invstd), M, N, eps, momentum,
+                                           self._stream())
+        _lib.check(st, "cg_bn_running_update")
+
     def bn_bwd(self, dX, dY, X, Y, PM, mean, invstd, gamma, dgamma, dbeta, accumulate, slope, gbar=None, gxbar=None):
         M, N = X.shape
         assert dX.shape == X.shape and dY.shape == X.shape

@@ -163,6 +163,16 @@ int cg_bn_fwd_seg(float* Y, int ldy, const float* X, int ldx, int seg_rows, int 
                   void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * The running-statistics update of a train-mode BatchNorm1d call (GAN_functions.py:60,63,89,93,117,121,166) on its
+ * own, from the batch statistics an earlier cg_bn_fwd of the SAME input stored (mean, invstd; M rows): what a second
+ * forward call on that input would do to running_mean / running_var.  For a caller that applies a network twice to
+ * one batch with unchanged weights (the generator step's first pass after the critic step's, :326-327 and :344-345)
+ * and reuses the deterministic part of the first call.  The batch variance is recovered as 1/invstd^2 - eps.
+ */
+int cg_bn_running_update(float* running_mean, float* running_var, const float* mean, const float* invstd,
+                         int M, int N, float eps, float momentum, void* stream);
+
+/*
  * Eval-mode BatchNorm1d + activation (g_m2h.eval() translation pass,
  * GAN_functions.py:461-468): Y = act(gamma*(x-rm)/sqrt(rv+eps)+beta).
  * ybf16 (may be NULL): bf16 image of Y, as in cg_bn_fwd.

@@ -187,6 +187,12 @@ class CpuOps:
         dW2 += wpart2.view(-1)[:256].view_as(dW2)
         dW1 += wpart1.view(-1)[:256].view_as(dW1)
 
+    def bn_running_update(self, rmean, rvar, mean, invstd, M, eps=1e-5, momentum=0.1):
+        """cg_bn_running_update: one more running-statistics update from stored batch statistics."""
+        var = (1.0 / (invstd.double() ** 2) - eps).clamp_min(0.0)
+        rmean.copy_((1 - momentum) * rmean + momentum * mean)
+        rvar.copy_((1 - momentum) * rvar + momentum * (var * (M / max(M - 1, 1))).to(rvar.dtype))
+
     def bn_eval(self, Y, X, gamma, beta, rmean, rvar, slope, eps=1e-5):
         h = (X - rmean) * (1.0 / torch.sqrt(rvar + eps)) * gamma + beta
         Y.copy_(torch.where(h > 0, h, h * slope))
