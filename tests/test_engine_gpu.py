@@ -335,6 +335,48 @@ def test_bf16_images_of_activations_change_no_bit(monkeypatch):
     assert all(o0[k] == o1[k] for k in LOSS_KEYS), (o0, o1)
 
 
+@pytest.mark.parametrize("lookahead", [False, True])
+def test_encoder_taken_over_from_the_critic_step_changes_no_parameter_bit(ops, lookahead):
+    """The generator step's first forward reuses the encoder state of the critic step's forward of the same batch
+    (GenPass.forward, encoder_of) instead of computing it again: same kernels on the same inputs, so every loss and
+    every parameter after several iterations is equal bit for bit with the reuse switched off; the encoder
+    BatchNorms' running variance, updated from the stored 1/invstd^2 - eps instead of the batch variance, agrees to
+    rounding (1e-6), their running mean and update counts exactly."""
+    from cycle_gan_rna_amd.engine import StepEngine
+    from cycle_gan_rna_amd.noise import DeviceNoise
+    cfg = O.default_config(preprocess_type="log_normalized", nb_critic=2)
+    nets, xm, xh, lm, lh = make_problem(300, 260, 4 * 64, cfg)
+    cm, ch = O.centroid_table(xm, lm, 12), O.centroid_table(xh, lh, 12)
+    data = [t.cuda() for t in (xm, xh, lm[:, None], lh[:, None])]
+    batch = lambda i: tuple(t[(i % 4) * 64:(i % 4 + 1) * 64] for t in data)  # noqa: E731
+    runs = []
+    for reuse in (True, False):
+        eng = StepEngine(nets, cfg, cm, ch, ops, 64)
+        eng.reuse_encoder = reuse
+        if lookahead:
+            eng.enable_concurrency()
+            eng.enable_lookahead()
+        noise = DeviceNoise("cuda:0", seed=3, default_generator=True)
+        outs = []
+        for i in range(5):
+            noise.begin_step()
+            outs.append(eng.iteration(i, *batch(i), noise, nxt=batch(i + 1)))
+        torch.cuda.synchronize()
+        runs.append((eng.arena_g.p.clone(), eng.arena_d.p.clone(), outs,
+                     {n: {k: v.clone() for k, v in net.B.items()} for n, net in eng.nets.items()},
+                     {n: dict(net.nbt) for n, net in eng.nets.items()}))
+    (g0, d0, o0, B0, n0), (g1, d1, o1, B1, n1) = runs
+    assert torch.equal(g0, g1) and torch.equal(d0, d1)
+    assert all(o0[i][k] == o1[i][k] for i in (0, 2, 4) for k in LOSS_KEYS)
+    assert n0 == n1
+    for n in B0:
+        for k in B0[n]:
+            if k.endswith("running_var") and n.startswith("g_") and k.startswith("encoder."):
+                assert rel(B0[n][k], B1[n][k]) <= 1e-6, (n, k)
+            else:
+                assert torch.equal(B0[n][k], B1[n][k]), (n, k)
+
+
 class KeyedNoise:
     """Noise whose values depend on what is drawn (kind, shape, how many of that kind and shape came before), not on
     how draws of different kinds interleave: two schedules that keep the order of calls within each kind see the
