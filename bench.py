@@ -203,8 +203,8 @@ def main():
     def step(i):
         s = (i % 16) * B
         noise.begin_step()
-        if eng.lookahead:      # the same iteration with the generators' forward passes issued ahead of the critics' work
-            eng.iteration(i, *batch(i), noise, nxt=batch(i + 1), metrics=False)
+        if not a.only:         # the loop body; with lookahead the generators' forward passes are issued ahead of the
+            eng.iteration(i, *batch(i), noise, nxt=batch(i + 1) if eng.lookahead else None, metrics=False)   # critics' work
             return
         if a.only != "g":
             eng.d_step(xm[s:s + B], xh[s:s + B], lm[s:s + B], lh[s:s + B], noise)
@@ -326,12 +326,7 @@ def main():
         def step16(i):
             s = (i % 16) * B
             noise.begin_step()
-            if eng16.lookahead:
-                eng16.iteration(i, *batch(i), noise, nxt=batch(i + 1), metrics=False)
-                return
-            eng16.d_step(xm[s:s + B], xh[s:s + B], lm[s:s + B], lh[s:s + B], noise)
-            if i % NB_CRITIC == 0:
-                eng16.g_step(xm[s:s + B], xh[s:s + B], lm[s:s + B], lh[s:s + B], noise)
+            eng16.iteration(i, *batch(i), noise, nxt=batch(i + 1) if eng16.lookahead else None, metrics=False)
         for i in range((2 * NB_CRITIC + 2 if eng16.lookahead else 2) if eng16.use_graphs else 0):
             step16(i if eng16.lookahead else 0)
         for i in range(a.warmup):
