@@ -49,7 +49,7 @@ SIGNATURES = {
     "cg_bn_running_update": ([P, P, P, P, I, I, F, F, P], I),
     "cg_bn_eval": ([P, I, P, I, I, I, P, P, P, P, F, F, P, I, P], I),
     "cg_bn_bwd": ([P, I, P, I, P, I, P, I, P, I, P, P, P, P, P, I, P, P, F, I, I, P, I, P, Z, P], I),
-    "cg_bn_bwd_bwd": ([P, I, P, I, P, I, P, I, P, I, P, I, P, P, P, P, P, I, I, P, P, Z, P], I),
+    "cg_bn_bwd_bwd": ([P, I, P, I, P, I, P, I, P, I, P, I, P, P, P, P, P, I, I, P, P, I, P, Z, P], I),
     "cg_axpby": ([P, I, F, P, I, F, P, I, I, I, P], I),
     "cg_mul": ([P, I, P, I, P, I, I, I, P], I),
     "cg_fill_coef": ([P, I, I, I, P, I, F, P], I),

@@ -422,7 +422,7 @@ __global__ void __launch_bounds__(256) bn_bb_apply(const double* ws, float* Vu, 
                                                    const float* U1, int ldu, const float* X, int ldx,
                                                    const float* mean, const float* invstd, const float* gamma,
                                                    const float* ubar, const float* mbar, int M, int N, int rows,
-                                                   u16* vhbf) {
+                                                   u16* vhbf, const float* PM, int ldpm) {
   __shared__ double lds[3 * RL * CW];
   BN_COMMON
   double s[3];
@@ -440,7 +440,8 @@ __global__ void __launch_bounds__(256) bn_bb_apply(const double* ws, float* Vu, 
     const float w = W[(size_t)m * ldw + col];
     const float u1 = U1[(size_t)m * ldu + col];
     const float xh = (X[(size_t)m * ldx + col] - mu) * is;
-    Vu[(size_t)m * ldvu + col] = k1 * (w - wbar - xh * r);
+    const float vu = k1 * (w - wbar - xh * r);
+    Vu[(size_t)m * ldvu + col] = PM ? vu * PM[(size_t)m * ldpm + col] : vu;
     const float vh = k2 * (mb * (w - wbar) + r * (u1 - ub) + xh * k3);
     Vh[(size_t)m * ldvh + col] = vh;
     if (vhbf) vhbf[(size_t)m * ldvh + col] = f2bf(vh);
@@ -605,8 +606,9 @@ extern "C" int cg_bn_bwd_seg(float* dX, int lddx, const float* dY, int lddy, con
 extern "C" int cg_bn_bwd_bwd(float* V_u1, int ldvu, float* V_h0, int ldvh, float* dgamma, int accumulate,
                              const float* W, int ldw, const float* U1, int ldu, const float* X, int ldx,
                              const float* mean, const float* invstd, const float* gamma, const float* ubar,
-                             const float* mbar, int M, int N, void* vh_bf16, void* workspace, size_t workspace_bytes,
-                             void* stream) {
+                             const float* mbar, int M, int N, void* vh_bf16, const float* PM, int ldpm, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+  if (PM && ldpm < N) return CG_ERR_BAD_ARG;
   if (!V_u1 || !V_h0 || !W || !U1 || !X || !mean || !invstd || !gamma || !ubar || !mbar || M <= 0 || N <= 0)
     return CG_ERR_BAD_ARG;
   if (ldvu < N || ldvh < N || ldw < N || ldu < N || ldx < N) return CG_ERR_BAD_ARG;
@@ -617,6 +619,6 @@ extern "C" int cg_bn_bwd_bwd(float* V_u1, int ldvu, float* V_h0, int ldvh, float
                      mean, invstd, M, N, g.rows);
   hipLaunchKernelGGL(bn_bb_apply, grid, dim3(256), 0, (hipStream_t)stream, (const double*)workspace, V_u1, ldvu, V_h0,
                      ldvh, dgamma, accumulate, W, ldw, U1, ldu, X, ldx, mean, invstd, gamma, ubar, mbar, M, N, g.rows,
-                     (u16*)vh_bf16);
+                     (u16*)vh_bf16, PM, ldpm);
   return cg_launch_status();
 }

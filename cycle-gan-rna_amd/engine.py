@@ -687,6 +687,7 @@ class CriticStack:
         self.zero_emb = Z(B, max(self.E, 1))
         self.demb_diff = Z(B, max(self.E, 1))
         self.alpha = None                       # the interpolation weights of the current critic step (forward)
+        self._dval_const = {}
         self.rowpen = Z(B)
         self.ubar, self.mbar = Z(1024), Z(1024)
         self.b, self.have_labels = 0, True
@@ -756,12 +757,14 @@ class CriticStack:
         assert self.nx == self.S
         ns = len(scales)
         R = ns * b
-        # Written on the device at every call: a captured step must carry these writes itself (a host-side "already
-        # holds these values" test would be frozen into the graph, and a batch of another size in between rewrites them).
-        for k, sc in enumerate(scales):
-            self.dval[k * b:(k + 1) * b].fill_(sc)
+        # The seed gradients: a buffer of their own per (batch size, scales), written once when first needed (an eager
+        # call: a step is captured at its second call) and never again, so a captured step reads constants and a
+        # batch of another size in between cannot disturb them.
+        key = (b, tuple(scales))
+        if key not in self._dval_const:
+            self._dval_const[key] = ops.to_device(torch.tensor(scales, dtype=torch.float32).repeat_interleave(b)[:, None])
         W1 = P["model.0.weight"]
-        dval, dh3 = self.dval[:R], self.g256[:R]
+        dval, dh3 = self._dval_const[key], self.g256[:R]
         ops.gemm(G["model.9.weight"], dval, self.a3[:R], True, False, accumulate=True)
         ops.colsum(G["model.9.bias"], dval, 1.0, True)
         ops.gemm(dh3, dval, P["model.9.weight"], False, False, epi=EPI_MUL, E=self.pm3[:R])
@@ -857,11 +860,9 @@ class CriticStack:
         ops.reduce_sum(red, slot, self.rowpen[:b])
         w = self.h1024a[:b]
         ops.gemm(w, ux, W1[:, :Gd], False, True)
-        vu1 = self.h1024b[:b]
-        ops.bn_bwd_bwd(vu1, vh0, G["model.1.weight"], True, w, u1, h0, mean, invstd, P["model.1.weight"], self.ubar,
-                       self.mbar)
-        t1 = vu1
-        ops.mul(t1, vu1, pm1)
+        t1 = self.h1024b[:b]        # V_u1 times the first layer's activation/dropout factor, in one pass
+        ops.bn_bwd_bwd(t1, vh0, G["model.1.weight"], True, w, u1, h0, mean, invstd, P["model.1.weight"], self.ubar,
+                       self.mbar, PM=pm1)
         ops.gemm(G["model.4.weight"], u2, t1, True, False, accumulate=True)
         t2 = self.h512[:b]
         ops.gemm(t2, t1, W2, False, True, epi=EPI_MUL, E=pm2)

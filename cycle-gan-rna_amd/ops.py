@@ -358,12 +358,15 @@ class HipOps:
                                 *self._bnws(M, N), self._stream())
         _lib.check(st, "cg_bn_bwd")
 
-    def bn_bwd_bwd(self, Vu, Vh, dgamma, accumulate, W, U1, X, mean, invstd, gamma, ubar, mbar):
+    def bn_bwd_bwd(self, Vu, Vh, dgamma, accumulate, W, U1, X, mean, invstd, gamma, ubar, mbar, PM=None):
+        """PM: Vu is stored multiplied by it (see cg_bn_bwd_bwd)."""
         M, N = X.shape
+        assert PM is None or PM.shape == X.shape
         assert Vu.shape == X.shape and Vh.shape == X.shape and W.shape == X.shape and U1.shape == X.shape
         st = self.lib.cg_bn_bwd_bwd(_ptr(Vu), _ld(Vu), _ptr(Vh), _ld(Vh), _ptr(dgamma), int(accumulate), _ptr(W),
                                     _ld(W), _ptr(U1), _ld(U1), _ptr(X), _ld(X), _ptr(mean), _ptr(invstd), _ptr(gamma),
-                                    _ptr(ubar), _ptr(mbar), M, N, self._twin(Vh)[0], *self._bnws(M, N), self._stream())
+                                    _ptr(ubar), _ptr(mbar), M, N, self._twin(Vh)[0], _ptr(PM), _ld(PM),
+                                    *self._bnws(M, N), self._stream())
         _lib.check(st, "cg_bn_bwd_bwd")
 
     # -- elementwise ------------------------------------------------------------

@@ -224,11 +224,13 @@ int cg_bn_bwd_seg(float* dX, int lddx, const float* dY, int lddy, const float* X
  *   V_h0 = -invstd^2*gamma*( m*(W-wbar) + r*(u1-ubar) + xhat*(q - wbar*ubar - 3*m*r) )
  *   dgamma (+)= M*invstd*(q - wbar*ubar - r*m)
  * vh_bf16 (may be NULL): bf16 image of V_h0 (leading dimension ldvh) for the weight-gradient product that reads it.
+ * PM (may be NULL): V_u1 is stored multiplied by it elementwise - the activation/dropout factor of the layer before
+ * the BatchNorm, which is all the chain does with V_u1 next (:167-168).
  */
 int cg_bn_bwd_bwd(float* V_u1, int ldvu, float* V_h0, int ldvh, float* dgamma, int accumulate,
                   const float* W, int ldw, const float* U1, int ldu, const float* X, int ldx,
                   const float* mean, const float* invstd, const float* gamma,
-                  const float* ubar, const float* mbar, int M, int N, void* vh_bf16,
+                  const float* ubar, const float* mbar, int M, int N, void* vh_bf16, const float* PM, int ldpm,
                   void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- elementwise / gather ------------------------------------------------ */

@@ -221,7 +221,7 @@ class CpuOps:
             gxbar.copy_(gxb)
         dX.copy_(invstd * gamma * (g - gb - xh * gxb))
 
-    def bn_bwd_bwd(self, Vu, Vh, dgamma, accumulate, W, U1, X, mean, invstd, gamma, ubar, mbar):
+    def bn_bwd_bwd(self, Vu, Vh, dgamma, accumulate, W, U1, X, mean, invstd, gamma, ubar, mbar, PM=None):
         M = X.shape[0]
         xh = (X - mean) * invstd
         wbar = (W.double().mean(0)).to(X.dtype)
@@ -230,7 +230,8 @@ class CpuOps:
         if dgamma is not None:
             d = (M * invstd.double() * (q.double() - wbar.double() * ubar.double() - r.double() * mbar.double())).to(X.dtype)
             dgamma.copy_((dgamma if accumulate else 0) + d)
-        Vu.copy_(invstd * gamma * (W - wbar - xh * r))
+        vu = invstd * gamma * (W - wbar - xh * r)
+        Vu.copy_(vu if PM is None else vu * PM)
         k3 = q - wbar * ubar - 3.0 * mbar * r
         Vh.copy_(-invstd * invstd * gamma * (mbar * (W - wbar) + r * (U1 - ubar) + xh * k3))
 
