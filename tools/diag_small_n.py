@@ -1,6 +1,8 @@
-"""Time the 3..16-column product (M x 12 x 1024, op(B) a column slice of a wide matrix) with HIP events, launches
-replayed back to back: contiguous B against B = W[:, G:] of a (1024, G + 12) matrix, cold (a 256 MB fill between
-launches evicts the caches) and warm.   usage: diag_small_n.py [M]"""
+"""Launch the 3..16-column product (M x 12 x 1024, op(B) a column slice of a wide matrix) a number of times, with
+contiguous B and with B = W[:, G:] of a (1024, G + 12) matrix, cold (a 256 MB fill between launches evicts the caches)
+and warm.  Meant to be run under `rocprofv3 --kernel-trace --stats` and read from the kernel's durations there: the
+HIP-event figures it prints include the host's launch latency whenever the GPU is idle when the launch arrives (about
+30 us through ctypes), which for a kernel of a few microseconds is most of the number.   usage: diag_small_n.py [M]"""
 import os
 import sys
 
