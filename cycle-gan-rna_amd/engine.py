@@ -406,13 +406,22 @@ class GenPass:
         if d_prev is not None:
             ops.gemm(d_prev, d_h0, P[lin + ".weight"], False, False)
 
-    def backward(self, d_out, need_dx=False, dx_out=None, dx_accumulate=False, kl=None, d_mu=None, d_lv=None):
+    def backward(self, d_out, need_dx=False, dx_out=None, dx_accumulate=False, kl=None, d_mu=None, d_lv=None,
+                 hook=None):
         """d_out: gradient w.r.t. the returned output.  kl = (coef, idx, weight)
         adds the KL term's gradient; d_mu / d_lv add gradients arriving at the
         returned mu / log_var.  Parameter gradients are accumulated into the
-        arena; returns dx (gradient w.r.t. the input) when need_dx."""
+        arena; returns dx (gradient w.r.t. the input) when need_dx.
+        hook (optional) is called with "decoder" once every decoder.* gradient (and the embedding table's) has
+        received this pass's contribution, with "middle" once everything but the encoder's first layer has, and with
+        "first" at the end - for a caller that starts the optimizer step on the parameters that are done."""
         self.backward_decoder(d_out)
-        return self.backward_rest(need_dx, dx_out, dx_accumulate, kl, d_mu, d_lv)
+        if hook is not None:
+            hook("decoder")
+        dx = self.backward_rest(need_dx, dx_out, dx_accumulate, kl, d_mu, d_lv, hook=hook)
+        if hook is not None:
+            hook("first")
+        return dx
 
     def backward_decoder(self, d_out):
         """First half of backward(): the decoder layers and the embedding table.  After it the gradients of every
@@ -436,7 +445,7 @@ class GenPass:
         if self.labels is not None:
             _embed_scatter(ops, G, ddi[:, L:], self.labels, True)
 
-    def backward_rest(self, need_dx=False, dx_out=None, dx_accumulate=False, kl=None, d_mu=None, d_lv=None):
+    def backward_rest(self, need_dx=False, dx_out=None, dx_accumulate=False, kl=None, d_mu=None, d_lv=None, hook=None):
         """Second half of backward(): latent blocks, the two heads, the encoder."""
         ops, P, G, L, b = self.ops, self.net.P, self.net.G, self.L, self.b
         nh = len(self.hidden)
@@ -491,6 +500,8 @@ class GenPass:
         ops.gemm(da, dml, self.W_ml, False, False)
         dx = None
         for li in reversed(range(nh)):
+            if li == 0 and hook is not None:
+                hook("middle")
             a_prev = self.enc_a[li - 1][:b] if li > 0 else self.x
             d_prev = self.d_act[li - 1][:b] if li > 0 else None
             self._bn_linear_bwd(self.d_act[li][:b], self.d_h0[li][:b], self.enc_h0[li][:b], self.enc_a[li][:b],
@@ -974,11 +985,13 @@ class EngineBase:
     adam_betas = (0.5, 0.9)
     adam_amsgrad = True
 
-    def _adam(self, arena):
+    def _adam(self, arena, lo=0, hi=None):
+        """The optimizer step on the element range [lo, hi) of the arena (default: all of it)."""
         b1, b2 = self.adam_betas
-        kw = {} if arena.p16 is None else dict(p16=arena.p16)
-        self.ops.adam(arena.p, arena.g, arena.m, arena.v, arena.vmax if self.adam_amsgrad else None, arena.lr_step,
-                      float(b1), float(b2), 1e-8, **kw)
+        sl = slice(lo, arena.n if hi is None else hi)
+        kw = {} if arena.p16 is None else dict(p16=arena.p16[sl])
+        self.ops.adam(arena.p[sl], arena.g[sl], arena.m[sl], arena.v[sl], arena.vmax[sl] if self.adam_amsgrad else None,
+                      arena.lr_step, float(b1), float(b2), 1e-8, **kw)
 
     # ---- HIP graphs ------------------------------------------------------------------
     def enable_graphs(self):
@@ -1444,7 +1457,12 @@ class StepEngine(EngineBase):
         def first(p, dfake, dcyc, whole):      # each side adds its cycle term inside its own branch
             ops.axpby(dfake, 1.0, dfake, 1.0, dcyc)
             if whole:
-                p.backward(dfake, kl=(coef, 4, 1.0))
+                # one rank: a network's optimizer step is issued range by range inside its backward branch, as soon
+                # as the range's gradients are complete (the cycle passes' contributions are in already) - bound by
+                # HBM, it runs beside the other network's products instead of alone after both branches
+                ranges = self._adam_stages()[p.net.name]
+                p.backward(dfake, kl=(coef, 4, 1.0),
+                           hook=lambda stage: [self._adam(self.arena_g, lo, hi) for lo, hi in ranges[stage]])
             else:
                 p.backward_decoder(dfake)
         # several ranks: the first passes' backward in two halves with a collective launched between
@@ -1476,11 +1494,33 @@ class StepEngine(EngineBase):
         self.sync.launch(self.arena_g.g, [(0, a0), (a1, b0), (b1, self.arena_g.n)])
         self.sync.wait()
 
+    _adam_stage_ranges = None
+
+    def _adam_stages(self):
+        """Per generator: the element ranges of the gradient arena whose optimizer step may start at each stage of
+        the first pass's backward (GenPass.backward, hook): "decoder" - decoder.* and whatever follows it in the
+        arena; "first" - the encoder's first Linear and its BatchNorm, and whatever precedes them; "middle" - the
+        rest."""
+        if self._adam_stage_ranges is None:
+            out = {}
+            for net in ("g_m2h", "g_h2m"):
+                lo_net, hi_net = self.arena_g.net_range[net]
+                keys = [(k, o, o + _pad4(n)) for (nn_, k), (o, n, _) in self.arena_g.offsets.items() if nn_ == net]
+                dec = [(o, h) for k, o, h in keys if k.startswith("decoder.")]
+                fst = [(o, h) for k, o, h in keys if k.startswith(("encoder.0.", "encoder.1."))]
+                d_lo, f_hi = min(o for o, _ in dec), max(h for _, h in fst)
+                assert f_hi <= d_lo and all(k.startswith("decoder.") or ".gate." in k for k, o, _ in keys if o >= d_lo)
+                assert all(k.startswith(("encoder.0.", "encoder.1.", "embeddings.")) for k, _, h in keys if h <= f_hi)
+                out[net] = {"decoder": [(d_lo, hi_net)], "middle": [(f_hi, d_lo)], "first": [(lo_net, f_hi)]}
+            self._adam_stage_ranges = out
+        return self._adam_stage_ranges
+
     def _g_update(self):
         ops = self.ops
         o = self._g_state[4]
         fake_human, fake_mouse = o["fh"], o["fm"]
-        self._adam(self.arena_g)
+        if self.sync.enabled:       # one rank: done range by range inside the backward branches (_g_backward)
+            self._adam(self.arena_g)
         self.fake_human, self.fake_mouse = fake_human, fake_mouse
 
     def set_loss_weights(self, weights):
