@@ -1267,6 +1267,8 @@ class StepEngine(EngineBase):
             ds.gp_backward(b, 2, cfg["lambda_gp"], self.red, slot)
             ds.backward_params(b, (-1.0 / b, 1.0 / b))
             ds.w1_grad(b)
+            if not self.sync.enabled:       # one rank: the critic's optimizer step at the end of its own branch,
+                self._adam(self.arena_d, *self.arena_d.net_range[name])     # beside the other critic's products
         self._many(lambda: backward("d_m", S_DM_REAL + 2), lambda: backward("d_h", S_DH_REAL + 2))
         ops.sum_parts(self.d_tot, self.red, self.d_slots, self.d_scales)
 
@@ -1285,7 +1287,8 @@ class StepEngine(EngineBase):
         return {name: self._critic_noise(noise, b, 3, alpha_before=2) for name in ("d_m", "d_h")}
 
     def _d_update(self):
-        self._adam(self.arena_d)
+        if self.sync.enabled:       # one rank: done in the critics' backward branches (_d_critics)
+            self._adam(self.arena_d)
 
     def d_losses(self):
         t = self.d_tot.cpu()

@@ -62,7 +62,7 @@ def test_two_rank_step_equals_gradient_averaging(tmp_path):
         """Runs the step of each shard but keeps the parameters frozen, collecting the gradients."""
     grads_d, grads_g = [], []
     for r, eng in enumerate(engines):
-        eng._adam = lambda arena: None
+        eng._adam = lambda arena, lo=0, hi=None: None
         torch.manual_seed(100 + r)
         noise = HostReplayNoise("cpu")
         sl = slice(r * b, (r + 1) * b)

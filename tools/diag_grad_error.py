@@ -52,9 +52,11 @@ def main():
     grabbed = {}
     real_adam = eng._adam
 
-    def adam(arena):
-        grabbed["d" if arena is eng.arena_d else "g"] = arena.g.clone()
-        real_adam(arena)
+    def adam(arena, lo=0, hi=None):      # the optimizer step is issued range by range
+        which = "d" if arena is eng.arena_d else "g"
+        hi = arena.n if hi is None else hi
+        grabbed.setdefault(which, torch.full_like(arena.g, float("nan")))[lo:hi] = arena.g[lo:hi]
+        real_adam(arena, lo, hi)
     eng._adam = adam
     torch.manual_seed(11)
     eng.iteration(0, xm.cuda(), xh.cuda(), lm2.cuda(), lh2.cuda(), HostReplayNoise("cuda:0"))
