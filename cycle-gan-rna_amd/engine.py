@@ -1253,9 +1253,7 @@ class StepEngine(EngineBase):
             val, _ = ds.forward(b, m1, m2, (0, 1, 2), interp=alpha if self.interp_by_linearity else None)
             ops.reduce_sum(self.red, s0, val[:b])
             ops.reduce_sum(self.red, s0 + 1, val[b:2 * b])
-        self._many(lambda: critic_fwd("d_m", mouse, mouse_cat, fake_mouse, human_cat, S_DM_REAL),
-                   lambda: critic_fwd("d_h", human, human_cat, fake_human, mouse_cat, S_DH_REAL))
-        # One backward branch per critic: its gradients cleared, the penalty's double-backward chain on the
+        # One branch per critic, forward and backward (nothing of one critic waits for the other): its gradients cleared, the penalty's double-backward chain on the
         # interpolates, the Wasserstein chain on the real and the generated rows, then the first layer's weight
         # gradient from what both left behind (CriticStack.w1_grad).  Every tensor is accumulated by one stream, so
         # there is no second gradient buffer and nothing to add afterwards.  (Four branches - the two chains of a
@@ -1269,7 +1267,12 @@ class StepEngine(EngineBase):
             ds.w1_grad(b)
             if not self.sync.enabled:       # one rank: the critic's optimizer step at the end of its own branch,
                 self._adam(self.arena_d, *self.arena_d.net_range[name])     # beside the other critic's products
-        self._many(lambda: backward("d_m", S_DM_REAL + 2), lambda: backward("d_h", S_DH_REAL + 2))
+
+        def critic(name, real, real_lab, fake, fake_lab, s0):
+            critic_fwd(name, real, real_lab, fake, fake_lab, s0)
+            backward(name, s0 + 2)
+        self._many(lambda: critic("d_m", mouse, mouse_cat, fake_mouse, human_cat, S_DM_REAL),
+                   lambda: critic("d_h", human, human_cat, fake_human, mouse_cat, S_DH_REAL))
         ops.sum_parts(self.d_tot, self.red, self.d_slots, self.d_scales)
 
     _d_noise = None      # masks and alpha of the critic step drawn before its critics' part is issued
