@@ -1167,8 +1167,8 @@ class StepEngine(EngineBase):
             pend = self._d_pending_lr is not None
             self._run_parts("d", b, ins, noise, [("graph", self._d_gen),
                                                  ("eager", self._d_wait_pending if pend else None),
-                                                 ("graph", self._d_apply_pending if pend else None),
-                                                 ("graph", self._d_critics), ("eager", self._d_launch_comm)])
+                                                 ("graph", self._d_apply_then_critics if pend else self._d_critics),
+                                                 ("eager", self._d_launch_comm)])
 
     def _run_parts(self, kind, b, tensors, noise, parts):
         """A step is a list of parts, ("graph", fn) for device work and ("eager", fn) for collectives and host
@@ -1313,10 +1313,8 @@ class StepEngine(EngineBase):
         # a captured generator step with the encoder taken over is a different graph from one that computes it
         self._run_parts("g" if self._g_encoder_of is None else "ge", b, (mouse, human, mouse_cat, human_cat), noise,
                         [("graph", self._g_first),
-                         ("eager", self._d_wait_pending if multi else None),      # the critics are needed from here on
-                         ("graph", self._d_apply_pending if multi else None),
-                         ("eager", self._d_clear_pending if multi else None),
-                         ("graph", self._g_rest),
+                         ("eager", self._d_wait_pending_clear if multi else None),   # the critics are needed from here on
+                         ("graph", self._d_apply_then_g_rest if multi else self._g_rest),
                          ("eager", self._g_loss_comm if self.sync.enabled else None),
                          ("graph", self._g_backward),
                          # several ranks: the decoders' gradients (complete first) are averaged while the rest of the
@@ -1326,7 +1324,18 @@ class StepEngine(EngineBase):
                          ("eager", self._g_grad_comm_rest if self.sync.enabled else None),
                          ("graph", self._g_update)])
 
-    def _d_clear_pending(self):
+    # Several ranks: the deferred critic update shares a HIP graph with the device work that follows it (one graph
+    # launch less per step than a graph of its own).
+    def _d_apply_then_critics(self):
+        self._d_apply_pending()
+        self._d_critics()
+
+    def _d_apply_then_g_rest(self):
+        self._d_apply_pending()
+        self._g_rest()
+
+    def _d_wait_pending_clear(self):
+        self._d_wait_pending()
         self._d_pending_lr = None
 
     def _g_first(self, mouse, human, mouse_cat, human_cat, noise):
