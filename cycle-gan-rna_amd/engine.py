@@ -993,6 +993,24 @@ class EngineBase:
         self.ops.adam(arena.p[sl], arena.g[sl], arena.m[sl], arena.v[sl], arena.vmax[sl] if self.adam_amsgrad else None,
                       arena.lr_step, float(b1), float(b2), 1e-8, **kw)
 
+    # ---- release -------------------------------------------------------------------
+    def close(self):
+        """Wait for the whole device, then let go of this engine's HIP graphs and events (nothing of the engine is
+        in flight when they are destroyed).  See _graphed() for the lifetime rule of a captured graph."""
+        dev = getattr(getattr(self, "ops", None), "device", None)
+        if dev is not None and dev.type == "cuda" and torch.cuda.is_initialized():
+            torch.cuda.synchronize(dev)
+        if getattr(self, "_graphs", None):
+            self._graphs = {}
+        self._edge_events = None
+        self._pin = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:       # interpreter shutdown: modules may be gone already
+            pass
+
     # ---- HIP graphs ------------------------------------------------------------------
     def enable_graphs(self):
         """Capture the device work of the critic step and of the generator step into HIP
@@ -1019,7 +1037,13 @@ class EngineBase:
             return
         if st["graph"] is None:
             before = {n: dict(net.nbt) for n, net in self.nets.items()}
-            g = torch.cuda.CUDAGraph()
+            # keep_graph: the captured graph lives as long as the executable graph made from it.  torch's default
+            # destroys it right after instantiation, and on this ROCm build destroying the executable graph later
+            # still touches the nodes of its source graph: when those had been freed, one 32-bit word was decremented
+            # and one cleared in whatever the host had allocated there since - a weight read back from the device,
+            # the next model's initial weights, a recorded loss - in 5 to 17 % of the runs of a training loop with
+            # forked graphs (fresh process, identity extension on), and in none of 280 with the source graph kept.
+            g = torch.cuda.CUDAGraph(keep_graph=True)
             # one capture stream per lane, with its scratch allocated beforehand: kernels captured on it take their
             # scratch by stream, and graphs of different lanes are replayed side by side
             lane = "ahead" if self._lane_sides is not None else "main"
@@ -1031,10 +1055,15 @@ class EngineBase:
             # a stream, an event) inside a capture aborts the process
             gc_was_on = gc.isenabled()
             gc.disable()
+            # the fork/join events of a capture are its own: an event recorded while capturing keeps references into
+            # that capture's graph, which is destroyed once the executable graph exists - they are kept (with the
+            # graph) and never recorded again
+            eager_events, self._edge_events = self._edge_events, {}
             try:
                 with torch.cuda.graph(g, stream=self._cap_streams[lane], capture_error_mode="thread_local"):
                     body(*st["static"], noise)
             finally:
+                st["events"], self._edge_events = self._edge_events, eager_events
                 if gc_was_on:
                     gc.enable()
             st["graph"] = g

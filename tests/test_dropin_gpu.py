@@ -228,8 +228,9 @@ def test_train_function_default_mode_replays_graphs(identity, iters_per_epoch):
         assert all(np.isfinite(v).all() for v in metrics.values())
         assert ("identity_loss" in metrics) == identity and (not identity or min(metrics["identity_loss"]) > 0)
         res[mode] = (metrics, mods[0].state_dict()["encoder.0.weight"].cpu())
-    differ = {k: (res["fast"][0][k], res["plain"][0][k]) for k in res["fast"][0] if res["fast"][0][k] != res["plain"][0][k]}
-    assert not differ, differ
+    differ = {k: [(i, float(a), float(b)) for i, (a, b) in enumerate(zip(res["fast"][0][k], res["plain"][0][k])) if a != b][:2]
+              for k in res["fast"][0] if res["fast"][0][k] != res["plain"][0][k]}
+    assert not differ, f"first (epoch, graphs, eager) that differ: {differ}"
     assert torch.equal(res["fast"][1], res["plain"][1])
 
 

@@ -31,7 +31,7 @@ def timeit(ops, C, A, B, ta, tb, acc, n=20):
         for _ in range(2):
             ops.gemm(C, A, B, bool(ta), bool(tb), accumulate=bool(acc))
     torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
+    g = torch.cuda.CUDAGraph(keep_graph=True)      # see EngineBase._graphed
     with torch.cuda.graph(g, stream=_STREAM):
         for _ in range(n):
             ops.gemm(C, A, B, bool(ta), bool(tb), accumulate=bool(acc))
