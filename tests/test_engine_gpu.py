@@ -168,6 +168,15 @@ def test_identity_loss_extension_matches_oracle(ops):
             out = e2.iteration(i, *dx, noise)
         torch.cuda.synchronize()
         finals.append((e2.arena_g.p.clone(), out["identity_loss"]))
+        if fast:
+            # every executable graph still holds the graph it was instantiated from (raw_cuda_graph() raises otherwise):
+            # destroying one whose source graph is gone damages host memory on this ROCm build (EngineBase._graphed)
+            assert e2._graphs and all(st["graph"].raw_cuda_graph() for st in e2._graphs.values() if st["graph"])
+            # host memory allocated between the captures and the engine's release keeps its contents through the release
+            canary = [torch.full((2048,), 0.0625 + k) for k in range(64)]
+            e2.close()
+            del e2
+            assert all(bool((c == 0.0625 + k).all()) for k, c in enumerate(canary))
     assert torch.equal(finals[0][0], finals[1][0]) and finals[0][1] == finals[1][1]
 
 
