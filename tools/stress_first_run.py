@@ -16,14 +16,15 @@ from oracle import cyclegan_oracle as O                             # noqa: E402
 fx = torch.load(os.path.join(T.GOLD, "function_level.pt"), weights_only=True)["one_iter_epochs"]
 gm, gh0, N = fx["g_mouse"], fx["g_human"], fx["N"]
 names = [f"type{i:02d}" for i in range(12)]
-lm, lh = O.balanced_labels(N, 12, 5), O.balanced_labels(N, 12, 6)
+NB = int(os.environ.get("STRESS_ITERS", 1)) * N          # cells per species: STRESS_ITERS iterations per epoch
+lm, lh = O.balanced_labels(NB, 12, 5), O.balanced_labels(NB, 12, 6)
 cat = np.concatenate([lm.numpy(), lh.numpy()])[:, None]
 
 
 def run(identity, **over):
     gh = gm if identity else gh0
-    xm, _ = O.synthetic_expression(N, gm, 12, seed=3)
-    xh, _ = O.synthetic_expression(N, gh, 12, seed=4)
+    xm, _ = O.synthetic_expression(NB, gm, 12, seed=3)
+    xh, _ = O.synthetic_expression(NB, gh, 12, seed=4)
     cfg = dict(fx["cfg"], device="cuda", progress=False, epochs=int(os.environ.get("STRESS_EPOCHS", 4)))
     cfg.update(over)
     if identity:
