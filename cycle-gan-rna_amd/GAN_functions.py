@@ -569,122 +569,125 @@ def train_enhanced_cycle_gan(g_m2h, g_h2m, d_m, d_h, mouse_adata, human_adata,
     eng = StepEngine({k: m.state_dict() for k, m in modules.items()}, config,
                      table(mouse_centroids, mouse_tensor.shape[1]), table(human_centroids, human_tensor.shape[1]),
                      ops, config['batch_size'])
-    if config.get('noise', 'device') == 'host_replay':
-        noise = HostReplayNoise(device)          # the reference's CPU draws, call by call (parity runs)
-    else:
-        # noise drawn in HBM from the default HIP generator (seeded from torch's global CPU generator, so
-        # torch.manual_seed still decides the run); the step is then replayed as HIP graphs and its independent
-        # branches run on side streams
-        noise = DeviceNoise(device, seed=int(torch.empty((), dtype=torch.int64).random_().item() % (2 ** 31)),
-                            default_generator=True)
-        if config.get('concurrent_streams', True):
-            eng.enable_concurrency()
-            if config.get('lookahead', True):
-                # the generators' forward of the next critic step is issued beside the critics' work of this one
-                eng.enable_lookahead()
-        if config.get('hip_graphs', True):
-            eng.enable_graphs()
-    metrics = {k: [] for k in ('g_loss', 'd_m_loss', 'd_h_loss', 'fake_human_var', 'fake_mouse_var', 'cycle_loss',
-                               'celltype_loss', 'fm_loss', 'kl_loss', 'current_lr')}
-    timestamp = datetime.now().strftime("%Y%m%d_%H%M")
-    output_dir = f"results/enhanced_cyclegan_{timestamp}"
-    os.makedirs(output_dir, exist_ok=True)
-    with open(os.path.join(output_dir, 'config.json'), 'w') as f:                              # :276-277
-        json.dump(config, f, indent=4)
-    use_wandb = config.get('use_wandb', False) and has_wandb
-    if use_wandb:
-        wandb.init(project="Grok_gene_cycleGAN_lr", config=config, name=f"run_{timestamp}")
-    verbose = config.get('progress', True)
-    epochs = range(config['epochs'])
-    if verbose:
-        try:
-            from tqdm import tqdm
-            epochs = tqdm(epochs, desc="Training")
-        except ImportError:
-            pass
-    key_map = (('g_loss', 'g_loss'), ('d_m_loss', 'd_m_loss'), ('d_h_loss', 'd_h_loss'), ('cycle_loss', 'cycle_loss'),
-               ('celltype_loss', 'celltype_loss'), ('fm_loss', 'fm_loss'), ('kl_loss', 'kl_loss'),
-               ('fake_human_var', 'fake_human_var'), ('fake_mouse_var', 'fake_mouse_var'))
-    if float(config.get('lambda_identity', 0.0)) > 0:          # extension (see StepEngine): reported with the others
-        key_map = key_map + (('identity_loss', 'identity_loss'),)
-        metrics['identity_loss'] = []
-    last = {}
-    for epoch in epochs:
-        acc = {k: [] for k, _ in key_map}
-        mouse_iter, human_iter = iter(mouse_loader), iter(human_loader)
-
-        def epoch_batches(mouse_iter=mouse_iter, human_iter=human_iter):
-            for i in range(max(len(mouse_loader), len(human_loader))):                         # :298-309
-                try:
-                    md, mc = next(mouse_iter)
-                except StopIteration:
-                    mouse_iter = iter(mouse_loader)
-                    md, mc = next(mouse_iter)
-                try:
-                    hd, hc = next(human_iter)
-                except StopIteration:
-                    human_iter = iter(human_loader)
-                    hd, hc = next(human_iter)
-                n = min(md.size(0), hd.size(0))                                                # :315-319
-                yield i, (md[:n], hd[:n], mc[:n], hc[:n])
-        # With lookahead one batch is drawn ahead of the iteration that uses it (within the epoch only), so that the
-        # engine can be told the next batch; the draws of the shuffling keep their order among themselves.  Without
-        # it every batch is drawn when its iteration starts, as in the reference: a loader that restarts in the
-        # middle of an epoch draws its new permutation from the global generator between the noise draws of two
-        # iterations, and replayed host noise ('noise': 'host_replay') must see exactly that order.
-        batches = epoch_batches()
-        cur = next(batches, None)
-        while cur is not None:
-            nxt = next(batches, None) if eng.lookahead else None
-            i, batch = cur
-            if hasattr(noise, "begin_step"):
-                noise.begin_step()
-            out = eng.iteration(i, *batch, noise, nxt=None if nxt is None else nxt[1])
-            if out:                                                                            # :411-419
-                last = out
-                for k, src in key_map:
-                    acc[k].append(out[src])
-            cur = nxt if eng.lookahead else next(batches, None)
-        if config['use_lr_decay']:                                                             # :421
-            current_lr, new_lr = _lr_decay_step(config, epoch)
-            if new_lr is not None:
-                eng.set_lr(new_lr)
+    try:      # the engine's HIP graphs and events are released when training ends, however it ends
+        if config.get('noise', 'device') == 'host_replay':
+            noise = HostReplayNoise(device)          # the reference's CPU draws, call by call (parity runs)
         else:
-            current_lr = config['lr']
-        for k, _ in key_map:
-            metrics[k].append(np.mean(acc[k]))
-        metrics['current_lr'].append(current_lr)
+            # noise drawn in HBM from the default HIP generator (seeded from torch's global CPU generator, so
+            # torch.manual_seed still decides the run); the step is then replayed as HIP graphs and its independent
+            # branches run on side streams
+            noise = DeviceNoise(device, seed=int(torch.empty((), dtype=torch.int64).random_().item() % (2 ** 31)),
+                                default_generator=True)
+            if config.get('concurrent_streams', True):
+                eng.enable_concurrency()
+                if config.get('lookahead', True):
+                    # the generators' forward of the next critic step is issued beside the critics' work of this one
+                    eng.enable_lookahead()
+            if config.get('hip_graphs', True):
+                eng.enable_graphs()
+        metrics = {k: [] for k in ('g_loss', 'd_m_loss', 'd_h_loss', 'fake_human_var', 'fake_mouse_var', 'cycle_loss',
+                                   'celltype_loss', 'fm_loss', 'kl_loss', 'current_lr')}
+        timestamp = datetime.now().strftime("%Y%m%d_%H%M")
+        output_dir = f"results/enhanced_cyclegan_{timestamp}"
+        os.makedirs(output_dir, exist_ok=True)
+        with open(os.path.join(output_dir, 'config.json'), 'w') as f:                              # :276-277
+            json.dump(config, f, indent=4)
+        use_wandb = config.get('use_wandb', False) and has_wandb
+        if use_wandb:
+            wandb.init(project="Grok_gene_cycleGAN_lr", config=config, name=f"run_{timestamp}")
+        verbose = config.get('progress', True)
+        epochs = range(config['epochs'])
         if verbose:
-            print(f"Epoch {epoch + 1}/{config['epochs']}: G Loss: {metrics['g_loss'][-1]:.4f}, "
-                  f"D_M Loss: {metrics['d_m_loss'][-1]:.4f}, D_H Loss: {metrics['d_h_loss'][-1]:.4f}, "
-                  f"KL Loss: {metrics['kl_loss'][-1]:.4f}, FM Loss: {metrics['fm_loss'][-1]:.4f}, "
-                  f"Cycle Loss: {metrics['cycle_loss'][-1]:.4f}, celltype Loss: {metrics['celltype_loss'][-1]:.4f}")
-        if use_wandb and last:
-            sc = last['scales']
-            wandb.log({'epoch': epoch + 1, 'G Loss': metrics['g_loss'][-1], 'D_M Loss': metrics['d_m_loss'][-1],
-                       'D_H Loss': metrics['d_h_loss'][-1], 'KL Loss': metrics['kl_loss'][-1],
-                       'FM Loss': metrics['fm_loss'][-1], 'Cycle Loss': metrics['cycle_loss'][-1],
-                       'Celltype Loss': metrics['celltype_loss'][-1],
-                       'Fake Human Variance': metrics['fake_human_var'][-1],
-                       'Fake Mouse Variance': metrics['fake_mouse_var'][-1],
-                       'Scaledadv': config['lambda_adv'] * sc['adv'] * last['g_adv'],
-                       'Scaled cycle': config['lambda_cycle'] * sc['cycle'] * last['cycle_loss'],
-                       'Scaled celltype': config['lambda_celltype'] * sc['celltype'] * last['celltype_loss'],
-                       'Scaled fm': config['lambda_fm'] * sc['fm'] * last['fm_loss'],
-                       'Scaled kl': config['lambda_kl'] * sc['kl'] * last['kl_loss'],
-                       'Current LR': metrics['current_lr']})
-        if (epoch + 1) % 10 == 0 or epoch == config['epochs'] - 1:                             # :460-540
-            _progress_figures(eng, ops, noise, config, epoch, output_dir, mouse_dev, mouse_cat_tensor, human_adata,
-                              human_centroids, human_umap_coords, umap_model, idx_to_cell_type, pca_model, scaler)
-        if (epoch + 1) % 20 == 0 or epoch == config['epochs'] - 1:                             # :542-546
-            for name in modules:
-                torch.save(eng.state_dict(name), os.path.join(output_dir, f'{name}_epoch_{epoch + 1}.pt'))
-    for name, m in modules.items():            # the reference trains its modules in place: hand the weights back
-        sd = eng.state_dict(name)
-        m.load_state_dict({k: v.to(next(m.parameters()).device) for k, v in sd.items()})
-    if use_wandb:
-        wandb.finish()
-    return metrics, output_dir
+            try:
+                from tqdm import tqdm
+                epochs = tqdm(epochs, desc="Training")
+            except ImportError:
+                pass
+        key_map = (('g_loss', 'g_loss'), ('d_m_loss', 'd_m_loss'), ('d_h_loss', 'd_h_loss'), ('cycle_loss', 'cycle_loss'),
+                   ('celltype_loss', 'celltype_loss'), ('fm_loss', 'fm_loss'), ('kl_loss', 'kl_loss'),
+                   ('fake_human_var', 'fake_human_var'), ('fake_mouse_var', 'fake_mouse_var'))
+        if float(config.get('lambda_identity', 0.0)) > 0:          # extension (see StepEngine): reported with the others
+            key_map = key_map + (('identity_loss', 'identity_loss'),)
+            metrics['identity_loss'] = []
+        last = {}
+        for epoch in epochs:
+            acc = {k: [] for k, _ in key_map}
+            mouse_iter, human_iter = iter(mouse_loader), iter(human_loader)
+
+            def epoch_batches(mouse_iter=mouse_iter, human_iter=human_iter):
+                for i in range(max(len(mouse_loader), len(human_loader))):                         # :298-309
+                    try:
+                        md, mc = next(mouse_iter)
+                    except StopIteration:
+                        mouse_iter = iter(mouse_loader)
+                        md, mc = next(mouse_iter)
+                    try:
+                        hd, hc = next(human_iter)
+                    except StopIteration:
+                        human_iter = iter(human_loader)
+                        hd, hc = next(human_iter)
+                    n = min(md.size(0), hd.size(0))                                                # :315-319
+                    yield i, (md[:n], hd[:n], mc[:n], hc[:n])
+            # With lookahead one batch is drawn ahead of the iteration that uses it (within the epoch only), so that the
+            # engine can be told the next batch; the draws of the shuffling keep their order among themselves.  Without
+            # it every batch is drawn when its iteration starts, as in the reference: a loader that restarts in the
+            # middle of an epoch draws its new permutation from the global generator between the noise draws of two
+            # iterations, and replayed host noise ('noise': 'host_replay') must see exactly that order.
+            batches = epoch_batches()
+            cur = next(batches, None)
+            while cur is not None:
+                nxt = next(batches, None) if eng.lookahead else None
+                i, batch = cur
+                if hasattr(noise, "begin_step"):
+                    noise.begin_step()
+                out = eng.iteration(i, *batch, noise, nxt=None if nxt is None else nxt[1])
+                if out:                                                                            # :411-419
+                    last = out
+                    for k, src in key_map:
+                        acc[k].append(out[src])
+                cur = nxt if eng.lookahead else next(batches, None)
+            if config['use_lr_decay']:                                                             # :421
+                current_lr, new_lr = _lr_decay_step(config, epoch)
+                if new_lr is not None:
+                    eng.set_lr(new_lr)
+            else:
+                current_lr = config['lr']
+            for k, _ in key_map:
+                metrics[k].append(np.mean(acc[k]))
+            metrics['current_lr'].append(current_lr)
+            if verbose:
+                print(f"Epoch {epoch + 1}/{config['epochs']}: G Loss: {metrics['g_loss'][-1]:.4f}, "
+                      f"D_M Loss: {metrics['d_m_loss'][-1]:.4f}, D_H Loss: {metrics['d_h_loss'][-1]:.4f}, "
+                      f"KL Loss: {metrics['kl_loss'][-1]:.4f}, FM Loss: {metrics['fm_loss'][-1]:.4f}, "
+                      f"Cycle Loss: {metrics['cycle_loss'][-1]:.4f}, celltype Loss: {metrics['celltype_loss'][-1]:.4f}")
+            if use_wandb and last:
+                sc = last['scales']
+                wandb.log({'epoch': epoch + 1, 'G Loss': metrics['g_loss'][-1], 'D_M Loss': metrics['d_m_loss'][-1],
+                           'D_H Loss': metrics['d_h_loss'][-1], 'KL Loss': metrics['kl_loss'][-1],
+                           'FM Loss': metrics['fm_loss'][-1], 'Cycle Loss': metrics['cycle_loss'][-1],
+                           'Celltype Loss': metrics['celltype_loss'][-1],
+                           'Fake Human Variance': metrics['fake_human_var'][-1],
+                           'Fake Mouse Variance': metrics['fake_mouse_var'][-1],
+                           'Scaledadv': config['lambda_adv'] * sc['adv'] * last['g_adv'],
+                           'Scaled cycle': config['lambda_cycle'] * sc['cycle'] * last['cycle_loss'],
+                           'Scaled celltype': config['lambda_celltype'] * sc['celltype'] * last['celltype_loss'],
+                           'Scaled fm': config['lambda_fm'] * sc['fm'] * last['fm_loss'],
+                           'Scaled kl': config['lambda_kl'] * sc['kl'] * last['kl_loss'],
+                           'Current LR': metrics['current_lr']})
+            if (epoch + 1) % 10 == 0 or epoch == config['epochs'] - 1:                             # :460-540
+                _progress_figures(eng, ops, noise, config, epoch, output_dir, mouse_dev, mouse_cat_tensor, human_adata,
+                                  human_centroids, human_umap_coords, umap_model, idx_to_cell_type, pca_model, scaler)
+            if (epoch + 1) % 20 == 0 or epoch == config['epochs'] - 1:                             # :542-546
+                for name in modules:
+                    torch.save(eng.state_dict(name), os.path.join(output_dir, f'{name}_epoch_{epoch + 1}.pt'))
+        for name, m in modules.items():            # the reference trains its modules in place: hand the weights back
+            sd = eng.state_dict(name)
+            m.load_state_dict({k: v.to(next(m.parameters()).device) for k, v in sd.items()})
+        if use_wandb:
+            wandb.finish()
+        return metrics, output_dir
+    finally:
+        eng.close()
 
 
 def _progress_figures(eng, ops, noise, config, epoch, output_dir, mouse_dev, mouse_cat, human_adata, human_centroids,

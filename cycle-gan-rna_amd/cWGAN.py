@@ -318,53 +318,56 @@ def train_gan(generator, discriminator, dataloader, cat_covs, num_covs, config, 
             sd = eng.state_dict(name)
             m.load_state_dict({k: v.to(next(m.parameters()).device) for k, v in sd.items()})
 
-    for epoch in range(config['epochs']):
-        if verbose:
-            print(f"\nEpoch [{epoch + 1}/{config['epochs']}]")
-        w = neg_weight(epoch)
-        eng.begin_log()
-        for batch_idx, (real,) in enumerate(loader):
-            real = real.to(device).float()
-            b = real.size(0)
-            idx = torch.randint(0, cat_covs.size(0), (b,)).to(device)
-            bc = cat_covs.index_select(0, idx)
-            bn = num_covs.index_select(0, idx) if num_covs.shape[1] else None
-            for _ in range(config['nb_critic']):
+    try:      # the engine's HIP graphs and events are released when training ends, however it ends
+        for epoch in range(config['epochs']):
+            if verbose:
+                print(f"\nEpoch [{epoch + 1}/{config['epochs']}]")
+            w = neg_weight(epoch)
+            eng.begin_log()
+            for batch_idx, (real,) in enumerate(loader):
+                real = real.to(device).float()
+                b = real.size(0)
+                idx = torch.randint(0, cat_covs.size(0), (b,)).to(device)
+                bc = cat_covs.index_select(0, idx)
+                bn = num_covs.index_select(0, idx) if num_covs.shape[1] else None
+                for _ in range(config['nb_critic']):
+                    if hasattr(noise, "begin_step"):
+                        noise.begin_step()
+                    eng.d_step(real, bc, bn, noise)
+                    eng.log("d")
                 if hasattr(noise, "begin_step"):
                     noise.begin_step()
-                eng.d_step(real, bc, bn, noise)
-                eng.log("d")
-            if hasattr(noise, "begin_step"):
-                noise.begin_step()
-            eng.g_step(b, bc, bn, noise)
-            eng.log("g")
-            if verbose and batch_idx % 10 == 0:
-                lo = eng.losses()
-                print(f"  Batch [{batch_idx}/{total_batches}] D_loss: {lo['d_loss']:.4f}, G_loss: {lo['g_loss']:.4f}, "
-                      f"G_main: {lo['g_loss_main']:.4f}, Neg_prop: 0.000, Neg_mag: 0.000, Neg_weight: {w:.3f}")
-        d_losses, g_losses = eng.end_log()
-        avg_d, avg_g = float(np.mean(d_losses)), float(np.mean(g_losses))
-        if verbose:
-            print(f"\nEpoch {epoch + 1} Summary:")
-            print(f"  Average D_loss: {avg_d:.4f}")
-            print(f"  Average G_loss: {avg_g:.4f}")
-            print(f"  Average G_main: {avg_g:.4f}")
-            print("  Average Neg_prop: 0.0000")
-            print("  Average Neg_mag: 0.0000")
-            print(f"  Negative Penalty Weight: {w:.4f}")
-        if wandb is not None and getattr(wandb, "run", None) is not None:
-            # the generator's output is relu(x) times a positive scale: the negative-value terms are identically zero
-            wandb.log({'epoch': epoch, 'd_loss': avg_d, 'g_loss': avg_g, 'g_loss_main': avg_g,
-                       'negative_proportion': 0.0, 'negative_magnitude': 0.0, 'negative_penalty_weight': w})
-        last = epoch == config['epochs'] - 1
-        if (score_fn is not None and epoch % 10 == 0) or (save_fn is not None and (epoch % 20 == 0 or last)):
-            hand_back()
-        if score_fn is not None and epoch % 10 == 0:
-            score = score_fn(generator)
+                eng.g_step(b, bc, bn, noise)
+                eng.log("g")
+                if verbose and batch_idx % 10 == 0:
+                    lo = eng.losses()
+                    print(f"  Batch [{batch_idx}/{total_batches}] D_loss: {lo['d_loss']:.4f}, G_loss: {lo['g_loss']:.4f}, "
+                          f"G_main: {lo['g_loss_main']:.4f}, Neg_prop: 0.000, Neg_mag: 0.000, Neg_weight: {w:.3f}")
+            d_losses, g_losses = eng.end_log()
+            avg_d, avg_g = float(np.mean(d_losses)), float(np.mean(g_losses))
             if verbose:
-                print(f'Epoch {epoch}: Score = {score:.4f}')
-        if save_fn is not None and epoch % 20 == 0:
-            save_fn(generator, discriminator, epoch)
-        if last and save_fn is not None:
-            save_fn(generator, discriminator, epoch)
-    hand_back()          # the notebook trains its modules in place
+                print(f"\nEpoch {epoch + 1} Summary:")
+                print(f"  Average D_loss: {avg_d:.4f}")
+                print(f"  Average G_loss: {avg_g:.4f}")
+                print(f"  Average G_main: {avg_g:.4f}")
+                print("  Average Neg_prop: 0.0000")
+                print("  Average Neg_mag: 0.0000")
+                print(f"  Negative Penalty Weight: {w:.4f}")
+            if wandb is not None and getattr(wandb, "run", None) is not None:
+                # the generator's output is relu(x) times a positive scale: the negative-value terms are identically zero
+                wandb.log({'epoch': epoch, 'd_loss': avg_d, 'g_loss': avg_g, 'g_loss_main': avg_g,
+                           'negative_proportion': 0.0, 'negative_magnitude': 0.0, 'negative_penalty_weight': w})
+            last = epoch == config['epochs'] - 1
+            if (score_fn is not None and epoch % 10 == 0) or (save_fn is not None and (epoch % 20 == 0 or last)):
+                hand_back()
+            if score_fn is not None and epoch % 10 == 0:
+                score = score_fn(generator)
+                if verbose:
+                    print(f'Epoch {epoch}: Score = {score:.4f}')
+            if save_fn is not None and epoch % 20 == 0:
+                save_fn(generator, discriminator, epoch)
+            if last and save_fn is not None:
+                save_fn(generator, discriminator, epoch)
+        hand_back()          # the notebook trains its modules in place
+    finally:
+        eng.close()

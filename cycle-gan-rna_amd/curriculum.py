@@ -371,6 +371,7 @@ class CurriculumTrainer:
         final, eng = self.train_with_curriculum(nets, config, curriculum, trial, epochs)
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
+        eng.close()             # the trial's HIP graphs and events
         final['train_seconds'] = time.time() - t0
         final['config'] = {k: v for k, v in config.items()}
         final['curriculum'] = curriculum

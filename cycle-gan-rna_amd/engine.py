@@ -23,9 +23,12 @@ Adam launch updates a whole optimizer; each named parameter is a view.
 """
 from __future__ import annotations
 
+import contextlib
 import gc
 import math
 import os
+import sys
+import warnings
 import weakref
 from collections import OrderedDict
 from typing import Dict, Optional
@@ -133,6 +136,14 @@ def _emb_tables(P):
         out.append((f"embeddings.{i}.weight", P[f"embeddings.{i}.weight"].shape[1]))
         i += 1
     return out
+
+
+def _zero(ops, view):
+    """view <- 0 through the backend when it keeps bf16 images of its workspaces (HipOps.zero), else in place."""
+    if hasattr(ops, "zero"):
+        ops.zero(view)
+    else:
+        view.zero_()
 
 
 def _embed_gather(ops, out, P, labels):
@@ -377,7 +388,7 @@ class GenPass:
         if labels is not None:
             _embed_gather(ops, dec_in[:, L:], P, labels)
         else:
-            dec_in[:, L:].zero_()
+            _zero(ops, dec_in[:, L:])
         a = dec_in
         for li in range(nh):
             self._linear_bn_relu(self.dec_a[li][:b], self.dec_h0[li][:b], self.dec_stats[li], a,
@@ -550,7 +561,7 @@ class DiscPass:
         if labels is not None:
             _embed_gather(ops, emb, P, labels)
         else:
-            emb.zero_()
+            _zero(ops, emb)
         h0 = self.h0[:b]
         ops.gemm(h0, x, W1[:, :Gd], False, True, bias=P["model.0.bias"])
         ops.gemm(h0, emb, W1[:, Gd:], False, True, accumulate=True)
@@ -736,7 +747,7 @@ class CriticStack:
             if self.have_labels:
                 _embed_gather(ops, self.emb[lo:hi], P, self.lab[lo:hi])
             else:
-                self.emb[lo:hi].zero_()
+                _zero(ops, self.emb[lo:hi])
         h0 = self.h0[:R]
         if interp is not None:
             assert self.gp_layout
@@ -883,6 +894,11 @@ class CriticStack:
         ops.colsum(G["model.9.weight"], vu3, 1.0, True)
 
 
+# graphs and events of engines that were dropped while a capture was running in the same thread: EngineBase.close()
+# releases them once no capture is running
+_DEFERRED_RELEASES = []
+
+
 class EngineBase:
     """Execution plumbing shared by the training engines: optimizer step on a flat arena, HIP-graph capture and
     replay of a step, independent branches on side streams.  A subclass provides self.ops, self.nets (name -> Net),
@@ -890,6 +906,7 @@ class EngineBase:
 
     use_graphs = False
     concurrent = False
+    _capture_single_stream = False
     _pin = None
     _lane_sides = None      # side streams of the lane that is issuing work (None: the main lane's self.sides)
 
@@ -995,21 +1012,41 @@ class EngineBase:
 
     # ---- release -------------------------------------------------------------------
     def close(self):
-        """Wait for the whole device, then let go of this engine's HIP graphs and events (nothing of the engine is
-        in flight when they are destroyed).  See _graphed() for the lifetime rule of a captured graph."""
+        """Let go of this engine's HIP graphs and events, in a fixed order and with nothing in flight: wait for the
+        device, destroy every executable graph with the graph it was made from, then the fork/join events recorded
+        inside the captures, then the eager fork/join events and the pinned upload ring.  Called by the training
+        functions when they are done with an engine; an engine dropped without it is released the same way when it
+        is collected (unless a graph capture is running in this thread: then the release waits for a later
+        collection of the parked state instead of synchronising the device inside the capture)."""
         dev = getattr(getattr(self, "ops", None), "device", None)
-        if dev is not None and dev.type == "cuda" and torch.cuda.is_initialized():
-            torch.cuda.synchronize(dev)
-        if getattr(self, "_graphs", None):
-            self._graphs = {}
-        self._edge_events = None
-        self._pin = None
+        graphs, self._graphs = getattr(self, "_graphs", None) or {}, {}
+        edge, self._edge_events = self._edge_events, None
+        pin, self._pin = self._pin, None
+        if dev is None or dev.type != "cuda" or not torch.cuda.is_initialized():
+            return
+        if torch.cuda.is_current_stream_capturing():
+            _DEFERRED_RELEASES.append((graphs, edge, pin))        # released by the next close() outside a capture
+            return
+        torch.cuda.synchronize(dev)
+        pending = _DEFERRED_RELEASES[:] + [(graphs, edge, pin)]
+        del _DEFERRED_RELEASES[:]
+        events = []
+        for graphs, _, _ in pending:
+            for st in graphs.values():
+                g = st.pop("graph", None)
+                events.append(st.pop("events", None))
+                if g is not None:
+                    g.reset()               # hipGraphExecDestroy, hipGraphDestroy, the capture's memory pool
+                del g
+                st.clear()
+        del events[:]                       # the captures' fork/join events, after every graph that recorded them
+        del pending[:], graphs, edge, pin   # the eager fork/join events and the upload ring
+        torch.cuda.synchronize(dev)
 
     def __del__(self):
-        try:
-            self.close()
-        except Exception:       # interpreter shutdown: modules may be gone already
-            pass
+        if sys.is_finalizing():             # interpreter shutdown: torch and the runtime may be half gone
+            return
+        self.close()
 
     # ---- HIP graphs ------------------------------------------------------------------
     def enable_graphs(self):
@@ -1021,6 +1058,12 @@ class EngineBase:
         self._graphs = {}
         self._cap_streams = {}
         self.use_graphs = True
+        ok, why = (self.ops.forked_graphs_supported() if hasattr(self.ops, "forked_graphs_supported") else (True, ""))
+        if self.concurrent and not ok:
+            # the branches of a step still run side by side when it is launched eagerly; its captured form is one
+            # chain of kernels on one stream
+            warnings.warn(why + "; the step's HIP graphs are captured on one stream (slower)", RuntimeWarning)
+            self._capture_single_stream = True
 
     def _graphed(self, kind, body, tensors, noise, static=None):
         """`static`: the fixed device buffers this graph reads its inputs from (default: buffers of its own).  Two
@@ -1037,12 +1080,8 @@ class EngineBase:
             return
         if st["graph"] is None:
             before = {n: dict(net.nbt) for n, net in self.nets.items()}
-            # keep_graph: the captured graph lives as long as the executable graph made from it.  torch's default
-            # destroys it right after instantiation, and on this ROCm build destroying the executable graph later
-            # still touches the nodes of its source graph: when those had been freed, one 32-bit word was decremented
-            # and one cleared in whatever the host had allocated there since - a weight read back from the device,
-            # the next model's initial weights, a recorded loss - in 5 to 17 % of the runs of a training loop with
-            # forked graphs (fresh process, identity extension on), and in none of 280 with the source graph kept.
+            # keep_graph: instantiation is a step of its own (g.instantiate() below) instead of a side effect of
+            # leaving the capture, so that it can run with the hardware queues levelled
             g = torch.cuda.CUDAGraph(keep_graph=True)
             # one capture stream per lane, with its scratch allocated beforehand: kernels captured on it take their
             # scratch by stream, and graphs of different lanes are replayed side by side
@@ -1055,14 +1094,23 @@ class EngineBase:
             # a stream, an event) inside a capture aborts the process
             gc_was_on = gc.isenabled()
             gc.disable()
-            # the fork/join events of a capture are its own: an event recorded while capturing keeps references into
-            # that capture's graph, which is destroyed once the executable graph exists - they are kept (with the
-            # graph) and never recorded again
+            # the fork/join events of a capture are its own: an event recorded while capturing refers to that
+            # capture's nodes - they are kept with the graph and never recorded again
             eager_events, self._edge_events = self._edge_events, {}
+            forked = self.concurrent and not self._capture_single_stream
+            was_concurrent = self.concurrent
+            if self._capture_single_stream:
+                self.concurrent = False             # every branch on the capture stream: a graph without forks
             try:
                 with torch.cuda.graph(g, stream=self._cap_streams[lane], capture_error_mode="thread_local"):
                     body(*st["static"], noise)
+                # A graph with parallel branches gets its internal streams when it is instantiated, and the runtime's
+                # launch code needs them on hardware queues other than the launch stream's (HipOps.level_hw_queues)
+                with (self.ops.level_hw_queues() if forked and hasattr(self.ops, "level_hw_queues")
+                      else contextlib.nullcontext()):
+                    g.instantiate()
             finally:
+                self.concurrent = was_concurrent
                 st["events"], self._edge_events = self._edge_events, eager_events
                 if gc_was_on:
                     gc.enable()
@@ -1718,8 +1766,11 @@ class StepEngine(EngineBase):
             # the critics' noise first: draws then come in the order of the plain schedule (critic step, then the
             # forward that follows it), so both schedules see the same numbers from one generator
             self._d_noise = self._draw_d_noise(noise, mouse.shape[0])
-            lanes = (self.ahead, self.ahead_sides[0])      # one generator each, both forked from the main stream
-            for st in lanes:
+            # one generator each, both forked from the main stream (or, when the step is being captured without
+            # forks, issued on the main stream like everything else)
+            single = self._capture_single_stream and torch.cuda.is_current_stream_capturing()
+            lanes = (main, main) if single else (self.ahead, self.ahead_sides[0])
+            for st in () if single else lanes:
                 self._after(st, main)
             passes = self.gen_a if mode == "g" else self.gen_d[1 - s]
             # the generator step's first forward follows the critic step's forward of the same batch (set s)
@@ -1733,7 +1784,7 @@ class StepEngine(EngineBase):
             else:
                 self._set_d_state(1 - s, (mouse, human, mouse_cat, human_cat, noise, out_h, out_m))
             self._d_crit_set(s)(noise)
-            for st in lanes:
+            for st in () if single else lanes:
                 self._after(main, st)
             if mode == "g":
                 self._g_tail(noise)

@@ -9,6 +9,7 @@ file, and there is no fallback when the library or the GPU is missing.
 from __future__ import annotations
 
 import bisect
+import contextlib
 import ctypes as C
 import os
 import weakref
@@ -71,6 +72,7 @@ class HipOps:
         # float32 arenas that have a bf16 shadow: (first byte, one past the last byte, shadow tensor)
         self._shadows = []
         self._shadow_los = []
+        self._retired_scratch = []
 
     def _ws(self):
         key = torch.cuda.current_stream(self.device).cuda_stream
@@ -108,8 +110,59 @@ class HipOps:
         ws = self._ws()
         need = self.lib.cg_bn_workspace_bytes(M, N) * nseg
         if need > ws[1].numel() * 8:
+            # A larger buffer replaces this stream's chunk-sum scratch.  A HIP graph captured earlier on this stream
+            # holds the old buffer's address, so the old buffer is kept for the life of the process instead of
+            # going back to the allocator; and nothing may be allocated while a capture is running.
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("BatchNorm scratch of %d bytes is needed inside a graph capture: run the step "
+                                   "once eagerly at this size first" % need)
+            self._retired_scratch.append(ws[1])
             ws[1] = torch.empty(need // 8 + 1, dtype=torch.float64, device=self.device)
         return C.c_void_p(ws[1].data_ptr()), ws[1].numel() * 8
+
+    # -- hardware queues and forked HIP graphs --------------------------------------
+    QUEUE_FILLERS = 32
+
+    @contextlib.contextmanager
+    def level_hw_queues(self):
+        """Everything that instantiates a HIP graph with parallel branches does it inside this context.
+
+        The HIP runtime gives such a graph up to four internal streams when it is instantiated and, at every launch,
+        uses all but one of them, skipping those that share the launch stream's hardware queue - without checking
+        that enough are left (two skipped = a read past the end of its stream list: a segmentation fault inside
+        hipGraphLaunch, or a branch run on a stale stream pointer, which showed as single words of host memory
+        changed).  A new stream joins the hardware queue that carries the fewest streams (the highest-numbered one
+        on a tie), so the four land on four different queues whenever the queues carry equally many - not after
+        streams have been destroyed unevenly, e.g. by an earlier engine's graphs.  QUEUE_FILLERS streams made first
+        fill the emptier queues and bring the choice back to its regular rotation; they are destroyed when the
+        context ends, the graph's internal streams keep their queues."""
+        n = 0 if os.environ.get("CGRNA_NO_QUEUE_LEVELLING") else self.QUEUE_FILLERS   # 0: debugging aid (the control)
+        handles = (C.c_void_p * max(n, 1))()
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.cg_queue_fillers_create(n, handles), "cg_queue_fillers_create")
+        try:
+            yield
+        finally:
+            with torch.cuda.device(self.device):
+                _lib.check(self.lib.cg_queue_fillers_destroy(n, handles), "cg_queue_fillers_destroy")
+
+    @staticmethod
+    def forked_graphs_supported():
+        """(ok, reason): False when the process's HIP settings leave a forked graph fewer hardware queues than
+        internal streams (GPU_MAX_HW_QUEUES below 4, or more graph streams than queues asked for with
+        DEBUG_HIP_FORCE_GRAPH_QUEUES): two of its streams then always share the launch stream's queue, which the
+        runtime's launch code does not survive (see level_hw_queues)."""
+        def env_int(name, default):
+            try:
+                return int(os.environ.get(name, default))
+            except ValueError:
+                return default
+        queues = env_int("GPU_MAX_HW_QUEUES", 4)
+        graph_streams = env_int("DEBUG_HIP_FORCE_GRAPH_QUEUES", 4)
+        if queues < 4 or graph_streams > queues:
+            return False, ("GPU_MAX_HW_QUEUES=%d with %d graph streams: a HIP graph with parallel branches cannot be "
+                           "launched safely" % (queues, graph_streams))
+        return True, ""
 
     # -- measurement: HIP events around every GEMM launch, on the launch stream ----------
     def begin_gemm_timing(self):
@@ -191,6 +244,22 @@ class HipOps:
         M, N = out.shape
         assert x.shape == out.shape
         _lib.check(self.lib.cg_copy_bf16(_ptr(out), c16, _ld(out), _ptr(x), _ld(x), M, N, self._stream()), "cg_copy_bf16")
+
+    def zero(self, out):
+        """out <- 0 (2-D), keeping the bf16 image of `out` up to date when it has one."""
+        c16, _ = self._twin(out)
+        if c16 is None:
+            out.zero_()
+            return
+        M, N = out.shape
+        z = getattr(self, "_zero_src", None)
+        if z is None or z.numel() < M * N:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("zero(): run the step once eagerly at this size before capturing it")
+            if z is not None:
+                self._retired_scratch.append(z)         # a captured graph may hold its address
+            z = self._zero_src = torch.zeros(M * N, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.cg_copy_bf16(_ptr(out), c16, _ld(out), _ptr(z), N, M, N, self._stream()), "cg_copy_bf16")
 
     def image_of(self, x, buf16):
         """A bf16 image of the float32 matrix `x` for gemm(..., a16= / b16=): the one the backend already keeps if `x`

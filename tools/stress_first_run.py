@@ -5,6 +5,10 @@ import os
 import sys
 import tempfile
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import faultdbg                                                     # noqa: E402
+faultdbg.install()       # a crash prints the native stack of the faulting thread and the Python frames of every thread
+
 import numpy as np
 import torch
 
@@ -71,8 +75,11 @@ if os.environ.get("STRESS_CHECK_READBACK"):
 # STRESS_OVER: a dict literal of configuration keys for the graph run, e.g. "dict(lookahead=False)"
 over = eval(os.environ.get("STRESS_OVER", "{}"))
 for identity in (False, True):
+    print("stage identity", identity, "graphs+streams start", flush=True)
     fast, wf = run(identity, **over)
+    print("stage identity", identity, "eager start", flush=True)
     plain, wp = run(identity, hip_graphs=False, concurrent_streams=False)
+    print("stage identity", identity, "compare", flush=True)
     d = {k: [i for i, (x, y) in enumerate(zip(fast[k], plain[k])) if x != y] for k in fast}
     d = {k: v for k, v in d.items() if v}
     w = [k for k in wf if not torch.equal(wf[k], wp[k])]
