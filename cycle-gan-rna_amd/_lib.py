@@ -84,8 +84,6 @@ SIGNATURES = {
     "cg_attn_bwd_blocks": ([I], I),
     "cg_attn_bwd_ws": ([I, I, I], C.c_longlong),
     "cg_attn_ln_bwd": ([P, P, P, P, P, P, P, I, I, I, I, P], I),
-    "cg_queue_fillers_create": ([I, C.POINTER(C.c_void_p)], I),
-    "cg_queue_fillers_destroy": ([I, C.POINTER(C.c_void_p)], I),
 }
 
 _lib = None

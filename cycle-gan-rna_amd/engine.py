@@ -23,7 +23,6 @@ Adam launch updates a whole optimizer; each named parameter is a view.
 """
 from __future__ import annotations
 
-import contextlib
 import gc
 import math
 import os
@@ -898,6 +897,27 @@ class CriticStack:
 # releases them once no capture is running
 _DEFERRED_RELEASES = []
 
+# This package never destroys a HIP stream, and therefore never destroys a HIP graph that has parallel branches.
+# Two defects of the HIP runtime (the libamdhip64 that ships with torch 2.10 + ROCm 7.0) are behind the rule:
+#  * Destroying a stream queues a last marker on it and waits for it on the host; the marker's completion handler,
+#    run later by the runtime's signal thread, still decrements a counter and clears a flag in the stream's device
+#    object (8 bytes at +0x98, 4 bytes at +0x378), which the destroying thread may have freed by then.  Whatever
+#    the host allocated there since - a weight read back from the device, the next model's initial weights, a
+#    recorded loss - has one word lowered by one and one word 736 bytes further set to zero; if the pages are gone
+#    the process dies of a segmentation fault in that thread.  A graph with parallel branches owns up to four
+#    internal streams, which hipGraphExecDestroy destroys.
+#  * At every launch such a graph uses all but one of its internal streams, skipping those that share the launch
+#    stream's hardware queue, without checking that enough are left.  A new stream joins the hardware queue that
+#    carries the fewest streams, so the internal streams land on different queues as long as the process only ever
+#    creates streams; after uneven destruction two of them can share the launch stream's queue, and the launch reads
+#    past the end of its stream list (a segmentation fault inside hipGraphLaunch).
+# Forked graphs of engines that are done are therefore parked here for the life of the process (with the fork/join
+# events recorded in their captures); a process may make MAX_FORKED_GRAPHS of them, later steps are captured on one
+# stream (a graph without internal streams, which is destroyed like any other object).
+_PARKED_FORKED_GRAPHS = []
+_forked_graphs_made = 0
+MAX_FORKED_GRAPHS = int(os.environ.get("CGRNA_MAX_FORKED_GRAPHS", "256"))
+
 
 class EngineBase:
     """Execution plumbing shared by the training engines: optimizer step on a flat arena, HIP-graph capture and
@@ -1013,11 +1033,12 @@ class EngineBase:
     # ---- release -------------------------------------------------------------------
     def close(self):
         """Let go of this engine's HIP graphs and events, in a fixed order and with nothing in flight: wait for the
-        device, destroy every executable graph with the graph it was made from, then the fork/join events recorded
-        inside the captures, then the eager fork/join events and the pinned upload ring.  Called by the training
-        functions when they are done with an engine; an engine dropped without it is released the same way when it
-        is collected (unless a graph capture is running in this thread: then the release waits for a later
-        collection of the parked state instead of synchronising the device inside the capture)."""
+        device; park every graph that has parallel branches, with the fork/join events of its capture (such a graph is
+        never destroyed, see _PARKED_FORKED_GRAPHS); destroy the others; then drop the eager fork/join events and
+        the pinned upload ring.  Called by the training functions when they are done with an engine; an engine
+        dropped without it is released the same way when it is collected (unless a graph capture is running in this
+        thread: the release then waits for the next close() outside a capture instead of synchronising the device
+        inside the capture)."""
         dev = getattr(getattr(self, "ops", None), "device", None)
         graphs, self._graphs = getattr(self, "_graphs", None) or {}, {}
         edge, self._edge_events = self._edge_events, None
@@ -1030,16 +1051,15 @@ class EngineBase:
         torch.cuda.synchronize(dev)
         pending = _DEFERRED_RELEASES[:] + [(graphs, edge, pin)]
         del _DEFERRED_RELEASES[:]
-        events = []
         for graphs, _, _ in pending:
             for st in graphs.values():
-                g = st.pop("graph", None)
-                events.append(st.pop("events", None))
-                if g is not None:
+                g, events = st.pop("graph", None), st.pop("events", None)
+                if g is not None and st.get("forked"):
+                    _PARKED_FORKED_GRAPHS.append((g, events))
+                elif g is not None:
                     g.reset()               # hipGraphExecDestroy, hipGraphDestroy, the capture's memory pool
-                del g
+                del g, events
                 st.clear()
-        del events[:]                       # the captures' fork/join events, after every graph that recorded them
         del pending[:], graphs, edge, pin   # the eager fork/join events and the upload ring
         torch.cuda.synchronize(dev)
 
@@ -1080,8 +1100,7 @@ class EngineBase:
             return
         if st["graph"] is None:
             before = {n: dict(net.nbt) for n, net in self.nets.items()}
-            # keep_graph: instantiation is a step of its own (g.instantiate() below) instead of a side effect of
-            # leaving the capture, so that it can run with the hardware queues levelled
+            # keep_graph: the captured graph stays with the executable graph made from it (g.instantiate() below)
             g = torch.cuda.CUDAGraph(keep_graph=True)
             # one capture stream per lane, with its scratch allocated beforehand: kernels captured on it take their
             # scratch by stream, and graphs of different lanes are replayed side by side
@@ -1097,6 +1116,11 @@ class EngineBase:
             # the fork/join events of a capture are its own: an event recorded while capturing refers to that
             # capture's nodes - they are kept with the graph and never recorded again
             eager_events, self._edge_events = self._edge_events, {}
+            global _forked_graphs_made
+            if self.concurrent and not self._capture_single_stream and _forked_graphs_made >= MAX_FORKED_GRAPHS:
+                warnings.warn("this process has made %d HIP graphs with parallel branches, which are never destroyed; "
+                              "further steps are captured on one stream (slower)" % _forked_graphs_made, RuntimeWarning)
+                self._capture_single_stream = True
             forked = self.concurrent and not self._capture_single_stream
             was_concurrent = self.concurrent
             if self._capture_single_stream:
@@ -1104,16 +1128,14 @@ class EngineBase:
             try:
                 with torch.cuda.graph(g, stream=self._cap_streams[lane], capture_error_mode="thread_local"):
                     body(*st["static"], noise)
-                # A graph with parallel branches gets its internal streams when it is instantiated, and the runtime's
-                # launch code needs them on hardware queues other than the launch stream's (HipOps.level_hw_queues)
-                with (self.ops.level_hw_queues() if forked and hasattr(self.ops, "level_hw_queues")
-                      else contextlib.nullcontext()):
-                    g.instantiate()
+                g.instantiate()
             finally:
                 self.concurrent = was_concurrent
                 st["events"], self._edge_events = self._edge_events, eager_events
                 if gc_was_on:
                     gc.enable()
+            st["forked"] = forked
+            _forked_graphs_made += int(forked)
             st["graph"] = g
             st["nbt"] = {n: {k: net.nbt[k] - before[n][k] for k in net.nbt} for n, net in self.nets.items()}
             g.replay()

@@ -9,7 +9,6 @@ file, and there is no fallback when the library or the GPU is missing.
 from __future__ import annotations
 
 import bisect
-import contextlib
 import ctypes as C
 import os
 import weakref
@@ -121,37 +120,14 @@ class HipOps:
         return C.c_void_p(ws[1].data_ptr()), ws[1].numel() * 8
 
     # -- hardware queues and forked HIP graphs --------------------------------------
-    QUEUE_FILLERS = 32
-
-    @contextlib.contextmanager
-    def level_hw_queues(self):
-        """Everything that instantiates a HIP graph with parallel branches does it inside this context.
-
-        The HIP runtime gives such a graph up to four internal streams when it is instantiated and, at every launch,
-        uses all but one of them, skipping those that share the launch stream's hardware queue - without checking
-        that enough are left (two skipped = a read past the end of its stream list: a segmentation fault inside
-        hipGraphLaunch, or a branch run on a stale stream pointer, which showed as single words of host memory
-        changed).  A new stream joins the hardware queue that carries the fewest streams (the highest-numbered one
-        on a tie), so the four land on four different queues whenever the queues carry equally many - not after
-        streams have been destroyed unevenly, e.g. by an earlier engine's graphs.  QUEUE_FILLERS streams made first
-        fill the emptier queues and bring the choice back to its regular rotation; they are destroyed when the
-        context ends, the graph's internal streams keep their queues."""
-        n = 0 if os.environ.get("CGRNA_NO_QUEUE_LEVELLING") else self.QUEUE_FILLERS   # 0: debugging aid (the control)
-        handles = (C.c_void_p * max(n, 1))()
-        with torch.cuda.device(self.device):
-            _lib.check(self.lib.cg_queue_fillers_create(n, handles), "cg_queue_fillers_create")
-        try:
-            yield
-        finally:
-            with torch.cuda.device(self.device):
-                _lib.check(self.lib.cg_queue_fillers_destroy(n, handles), "cg_queue_fillers_destroy")
-
     @staticmethod
     def forked_graphs_supported():
         """(ok, reason): False when the process's HIP settings leave a forked graph fewer hardware queues than
         internal streams (GPU_MAX_HW_QUEUES below 4, or more graph streams than queues asked for with
         DEBUG_HIP_FORCE_GRAPH_QUEUES): two of its streams then always share the launch stream's queue, which the
-        runtime's launch code does not survive (see level_hw_queues)."""
+        runtime's launch code does not survive: at every launch it uses all but one of the graph's (up to four)
+        internal streams, skipping those that share the launch stream's hardware queue, without checking that enough
+        are left, and reads past the end of its stream list."""
         def env_int(name, default):
             try:
                 return int(os.environ.get(name, default))

@@ -501,29 +501,6 @@ long long cg_attn_bwd_ws(int n_cells, int E, int heads);
 int cg_attn_ln_bwd(float* dX, float* dparams, float* wpart, const float* dY, const float* X, const float* keep,
                    const float* params, int n_cells, int E, int heads, int accumulate, void* stream);
 
-/*
- * Hardware-queue levelling around the instantiation of a forked HIP graph.  No counterpart in the reference, which
- * launches aten kernels one by one (GAN_functions.py:298-419); it exists because the captured training step runs
- * its independent branches (the two generators, the two critics, ...) as branches of one HIP graph.
- *
- * Why: when a graph with parallel branches is instantiated, the HIP runtime creates one internal stream per branch
- * level (at most 4), and at every hipGraphLaunch it uses all but one of them, skipping those that share the launch
- * stream's hardware queue - without checking that enough are left.  A new stream joins the hardware queue that
- * carries the fewest streams, so the internal streams land on distinct queues as long as the queues carry equally
- * many; after streams have been destroyed (a previous graph's, for one) two of them can land on the launch stream's
- * queue, and the launch then reads past the end of its stream list: a crash inside hipGraphLaunch, or a branch run
- * on whatever stale stream pointer lies there.  Creating `n` streams first fills the emptier queues (n >= the
- * imbalance + 3 brings the runtime's choice back to its regular rotation), the graph is instantiated, and the
- * fillers are destroyed again: the graph's internal streams keep their queues.
- *
- *   cg_queue_fillers_create(n, out): creates n non-blocking HIP streams on the current device, handles to out[0..n)
- *   cg_queue_fillers_destroy(n, h):  destroys them (NULL entries are skipped) and clears the handles
- * 0 <= n <= CG_MAX_QUEUE_FILLERS.  Neither call touches device memory or enqueues work.
- */
-#define CG_MAX_QUEUE_FILLERS 256
-int cg_queue_fillers_create(int n, void** out);
-int cg_queue_fillers_destroy(int n, void** handles);
-
 #ifdef __cplusplus
 }
 #endif

@@ -9,19 +9,15 @@ pattern: comma-separated indices of the raw streams to destroy before the graph 
 "auto": the two raw streams that share the null stream's hardware queue, which leaves that queue two streams short.
 
 Environment: DIAG_GRAPH=1 capture a graph with four branches, instantiate it after the destruction and replay it from
-the null stream; DIAG_NO_AFTER=1 make no further streams between the destruction and the instantiation;
-DIAG_LEVEL=1 instantiate inside HipOps.level_hw_queues().  "auto" with DIAG_GRAPH=1 DIAG_NO_AFTER=1 and without
-DIAG_LEVEL ends in a segmentation fault inside hipGraphLaunch (two of the graph's four internal streams land on the
-null stream's queue); with DIAG_LEVEL=1 it runs and prints "done".
+the null stream; DIAG_NO_AFTER=1 make no further streams between the destruction and the instantiation.  "auto" with DIAG_GRAPH=1
+DIAG_NO_AFTER=1 ends in a segmentation fault inside hipGraphLaunch: two of the graph's four internal streams land on
+the null stream's queue, and the launch reads past the end of its stream list.
 """
-import contextlib
 import ctypes
 import os
 import sys
 
 import torch
-
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
 dev = torch.device("cuda:0")
@@ -105,12 +101,7 @@ if os.environ.get("DIAG_GRAPH"):
                 ev[3 + k].record(s)
             cap.wait_event(ev[3 + k])
         x[:260 * UNIT].fill_(4.0)
-    level = contextlib.nullcontext()
-    if os.environ.get("DIAG_LEVEL"):
-        from cycle_gan_rna_amd.ops import HipOps
-        level = HipOps(dev).level_hw_queues()
-    with level:
-        g.instantiate()
+    g.instantiate()
     torch.cuda.synchronize()
     mark("before replay on the null stream", 6000)
     for _ in range(3):
