@@ -49,6 +49,8 @@ SIGNATURES = {
     "cg_bn_running_update": ([P, P, P, P, I, I, F, F, P], I),
     "cg_bn_eval": ([P, I, P, I, I, I, P, P, P, P, F, F, P, I, P], I),
     "cg_bn_bwd": ([P, I, P, I, P, I, P, I, P, I, P, P, P, P, P, I, P, P, F, I, I, P, I, P, Z, P], I),
+    "cg_bn_bwd_slabs_ok": ([I, I], I),
+    "cg_bn_bwd_slabs": ([P, I, P, I, P, I, P, I, P, I, P, P, P, P, P, I, F, I, I, P, I, P], I),
     "cg_bn_bwd_bwd": ([P, I, P, I, P, I, P, I, P, I, P, I, P, P, P, P, P, I, I, P, P, I, P, Z, P], I),
     "cg_axpby": ([P, I, F, P, I, F, P, I, I, I, P], I),
     "cg_mul": ([P, I, P, I, P, I, I, I, P], I),
@@ -84,6 +86,8 @@ SIGNATURES = {
     "cg_attn_bwd_blocks": ([I], I),
     "cg_attn_bwd_ws": ([I, I, I], C.c_longlong),
     "cg_attn_ln_bwd": ([P, P, P, P, P, P, P, I, I, I, I, P], I),
+    "cg_gemm_timing_begin": ([I], I),
+    "cg_gemm_timing_end": ([C.POINTER(C.c_float), I], I),
 }
 
 _lib = None

@@ -341,13 +341,16 @@ __global__ void __launch_bounds__(256) bn_fwd_fused(float* Y, int ldy, float* X,
   }
 }
 
-template <int CWF, int NR>
+// SLABS: the incoming gradient is not in dY yet but in `nslab` split-K partial sums of the product that makes it (dY
+// then points at dense M x N slabs, one after the other); they are added in slab order, as splitk_reduce_kernel of
+// gemm.hip adds them (a product without bias).
+template <int CWF, int NR, bool SLABS>
 __global__ void __launch_bounds__(256) bn_bwd_fused(float* dX, int lddx, const float* dY, int lddy, const float* X,
                                                     int ldx, const float* Y, int ldy, const float* PM, int ldpm,
                                                     const float* mean, const float* invstd, const float* gamma,
                                                     float* dgamma, float* dbeta, int accumulate, float* gbar_out,
                                                     float* gxbar_out, float slope, int M, int N, u16* dxbf,
-                                                    int lddxbf) {
+                                                    int lddxbf, int nslab) {
   constexpr int LANES = 256 / CWF;
   __shared__ double lds[2 * 256];
   const int c = threadIdx.x % CWF, r0 = threadIdx.x / CWF, col = blockIdx.x * CWF + c;
@@ -355,8 +358,18 @@ __global__ void __launch_bounds__(256) bn_bwd_fused(float* dX, int lddx, const f
   const float mu = ok ? mean[col] : 0.f, is = ok ? invstd[col] : 0.f;
   const int colc = min(col, N - 1);       // unconditional loads, see bn_fwd_fused
   float g[NR], xh[NR];
+  if (!SLABS) {
 #pragma unroll
-  for (int i = 0; i < NR; ++i) g[i] = dY[(size_t)min(r0 + i * LANES, M - 1) * lddy + colc];
+    for (int i = 0; i < NR; ++i) g[i] = dY[(size_t)min(r0 + i * LANES, M - 1) * lddy + colc];
+  } else {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) g[i] = 0.f;
+    for (int k = 0; k < nslab; ++k) {
+      const float* sl = dY + (size_t)k * M * N;
+#pragma unroll
+      for (int i = 0; i < NR; ++i) g[i] += sl[(size_t)min(r0 + i * LANES, M - 1) * N + colc];
+    }
+  }
 #pragma unroll
   for (int i = 0; i < NR; ++i) xh[i] = X[(size_t)min(r0 + i * LANES, M - 1) * ldx + colc];
   if (PM) {
@@ -588,9 +601,9 @@ extern "C" int cg_bn_bwd_seg(float* dX, int lddx, const float* dY, int lddy, con
   if (lddx < N || lddy < N || ldx < N || (Y && ldy < N) || (PM && ldpm < N) || (dxbf16 && lddxbf16 < N)) return CG_ERR_BAD_ARG;
   if (!workspace || workspace_bytes < nseg * cg_bn_workspace_bytes(M, N)) return CG_ERR_WORKSPACE;
   if (nseg == 1 && M <= 512 && N >= 256) {      // one launch (see bn_bwd_fused)
-    hipLaunchKernelGGL((bn_bwd_fused<16, 32>), dim3((N + 15) / 16), dim3(256), 0, (hipStream_t)stream, dX, lddx, dY,
-                       lddy, X, ldx, Y, ldy, PM, ldpm, mean, invstd, gamma, dgamma, dbeta, accumulate, gbar_out,
-                       gxbar_out, slope, M, N, (u16*)dxbf16, lddxbf16);
+    hipLaunchKernelGGL((bn_bwd_fused<16, 32, false>), dim3((N + 15) / 16), dim3(256), 0, (hipStream_t)stream, dX, lddx,
+                       dY, lddy, X, ldx, Y, ldy, PM, ldpm, mean, invstd, gamma, dgamma, dbeta, accumulate, gbar_out,
+                       gxbar_out, slope, M, N, (u16*)dxbf16, lddxbf16, 0);
     return cg_launch_status();
   }
   const Geo g = geo(M, N);
@@ -600,6 +613,21 @@ extern "C" int cg_bn_bwd_seg(float* dX, int lddx, const float* dY, int lddy, con
   hipLaunchKernelGGL(bn_bwd_apply, grid, dim3(256), 0, (hipStream_t)stream, (const double*)workspace, dX, lddx, dY,
                      lddy, X, ldx, Y, ldy, PM, ldpm, mean, invstd, gamma, dgamma, dbeta, accumulate, gbar_out,
                      gxbar_out, slope, M, N, g.rows, (u16*)dxbf16, lddxbf16);
+  return cg_launch_status();
+}
+
+extern "C" int cg_bn_bwd_slabs_ok(int M, int N) { return M > 0 && M <= 512 && N >= 256; }
+
+extern "C" int cg_bn_bwd_slabs(float* dX, int lddx, const float* slabs, int n_slabs, const float* X, int ldx,
+                               const float* Y, int ldy, const float* PM, int ldpm, const float* mean,
+                               const float* invstd, const float* gamma, float* dgamma, float* dbeta, int accumulate,
+                               float slope, int M, int N, void* dxbf16, int lddxbf16, void* stream) {
+  if (!dX || !slabs || !X || !mean || !invstd || !gamma || M <= 0 || N <= 0 || n_slabs < 1) return CG_ERR_BAD_ARG;
+  if (lddx < N || ldx < N || (Y && ldy < N) || (PM && ldpm < N) || (dxbf16 && lddxbf16 < N)) return CG_ERR_BAD_ARG;
+  if (!cg_bn_bwd_slabs_ok(M, N)) return CG_ERR_UNSUPPORTED;      // only the one-launch form reads slabs
+  hipLaunchKernelGGL((bn_bwd_fused<16, 32, true>), dim3((N + 15) / 16), dim3(256), 0, (hipStream_t)stream, dX, lddx,
+                     slabs, N, X, ldx, Y, ldy, PM, ldpm, mean, invstd, gamma, dgamma, dbeta, accumulate,
+                     (float*)nullptr, (float*)nullptr, slope, M, N, (u16*)dxbf16, lddxbf16, n_slabs);
   return cg_launch_status();
 }
 

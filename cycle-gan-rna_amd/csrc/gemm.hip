@@ -14,8 +14,58 @@
 // sum covers every k exactly once whatever the storage.
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
+#include <hip/hip_ext.h>
 #include "common.h"
 #include "gemm_tuned.h"
+
+// ------------------------------------------------------------------------------------------------
+// Measurement aid (cg_gemm_timing_begin / _end): while a recording is open on the calling thread, the first kernel
+// of every cg_gemm* call carries a start event and its last kernel (the split-K slab reduce, when there is one) a
+// stop event, attached to the dispatches themselves (hipExtLaunchKernelGGL), so that the elapsed time of a pair is
+// the device time from the first kernel's start to the last kernel's end.
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct GemmTiming {
+  std::vector<hipEvent_t> ev;     // start/stop pairs, one per call
+  std::vector<char> state;        // per call: bit 0 start attached, bit 1 stop attached
+  size_t calls = 0;
+  bool open = false;
+  hipEvent_t start = nullptr, stop = nullptr;     // of the call in progress, until a launch takes them
+};
+thread_local GemmTiming tl_timing;
+
+inline void timing_begin_call() {
+  GemmTiming& t = tl_timing;
+  t.start = t.stop = nullptr;
+  if (!t.open || 2 * (t.calls + 1) > t.ev.size()) return;
+  t.start = t.ev[2 * t.calls];
+  t.stop = t.ev[2 * t.calls + 1];
+  t.calls += 1;
+}
+inline hipEvent_t timing_take_start() {
+  GemmTiming& t = tl_timing;
+  hipEvent_t e = t.start;
+  if (e) { t.start = nullptr; t.state[t.calls - 1] |= 1; }
+  return e;
+}
+inline hipEvent_t timing_take_stop(bool last) {
+  GemmTiming& t = tl_timing;
+  if (!last) return nullptr;
+  hipEvent_t e = t.stop;
+  if (e) { t.stop = nullptr; t.state[t.calls - 1] |= 2; }
+  return e;
+}
+}  // namespace
+// A kernel launch of cg_gemm*: `last` says whether the call launches nothing after it.
+// (the plain launch whenever no recording is open, so that captured steps hold ordinary kernel nodes)
+#define CG_GEMM_LAUNCH(last, kernel, grid, block, st, ...)                                                            \
+  do {                                                                                                               \
+    if (tl_timing.open)                                                                                              \
+      hipExtLaunchKernelGGL(kernel, grid, block, 0, st, timing_take_start(), timing_take_stop(last), 0, __VA_ARGS__); \
+    else                                                                                                             \
+      hipLaunchKernelGGL(kernel, grid, block, 0, st, __VA_ARGS__);                                                   \
+  } while (0)
 
 #ifndef CG_PF_SMALL
 #define CG_PF_SMALL 2
@@ -1027,23 +1077,23 @@ bool launch_small(const GemmArgs& g, int transA, int transB, hipStream_t st) {
   if (g.K <= 16) {
     size_t blocks = ((size_t)g.M * g.N + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(gemm_small_k_kernel, dim3((unsigned)blocks), dim3(256), 0, st, g, s);
+    CG_GEMM_LAUNCH(true, gemm_small_k_kernel, dim3((unsigned)blocks), dim3(256), st, g, s);
     return true;
   }
   if (g.M <= 2 && transA && !transB) {
-    hipLaunchKernelGGL(gemm_small_m_kernel, dim3((g.N + 31) / 32), dim3(1024), 0, st, g);
+    CG_GEMM_LAUNCH(true, gemm_small_m_kernel, dim3((g.N + 31) / 32), dim3(1024), st, g);
     return true;
   }
   // a few columns: every wave reads B once per row it owns, which stays cheap while B is a few vectors (measured:
   // the one-column head 7 us against 13 us for the tiled kernel; twelve columns 40 us against 13 us)
   if (g.N <= 2 && !transA) {
-    hipLaunchKernelGGL(gemm_small_n_kernel, dim3((g.M + 3) / 4), dim3(256), 0, st, g, s);
+    CG_GEMM_LAUNCH(true, gemm_small_n_kernel, dim3((g.M + 3) / 4), dim3(256), st, g, s);
     return true;
   }
   if (g.N <= 16 && !transA) {
     const bool v4 = (uintptr_t)g.A % 16 == 0 && g.lda % 4 == 0 && g.K % 4 == 0;
-    if (v4) hipLaunchKernelGGL(gemm_small_n16_kernel<true>, dim3((g.M + SN_ROWS - 1) / SN_ROWS), dim3(256), 0, st, g, s);
-    else hipLaunchKernelGGL(gemm_small_n16_kernel<false>, dim3((g.M + SN_ROWS - 1) / SN_ROWS), dim3(256), 0, st, g, s);
+    if (v4) CG_GEMM_LAUNCH(true, gemm_small_n16_kernel<true>, dim3((g.M + SN_ROWS - 1) / SN_ROWS), dim3(256), st, g, s);
+    else CG_GEMM_LAUNCH(true, gemm_small_n16_kernel<false>, dim3((g.M + SN_ROWS - 1) / SN_ROWS), dim3(256), st, g, s);
     return true;
   }
   return false;
@@ -1056,8 +1106,8 @@ void launch_splitk_reduce(const GemmArgs& g, int splits, hipStream_t st) {
                   (uintptr_t)g.C16 % 8 == 0;
   int blocks = (int)((total / (v4 ? 4 : 1) + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  if (v4) hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(blocks), dim3(256), 0, st, g, splits);
-  else hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(blocks), dim3(256), 0, st, g, splits);
+  if (v4) CG_GEMM_LAUNCH(true, splitk_reduce_kernel<true>, dim3(blocks), dim3(256), st, g, splits);
+  else CG_GEMM_LAUNCH(true, splitk_reduce_kernel<false>, dim3(blocks), dim3(256), st, g, splits);
 }
 
 // keep != nullptr: the caller combines the split-K slabs itself (cg_gemm_slabs): no reduce launch, *keep = slabs
@@ -1072,14 +1122,15 @@ int launch_f32(const GemmArgs& g, int transA, int transB, bool vec, hipStream_t 
   splits = (nk + a.kt_per_split - 1) / a.kt_per_split;   // no empty split
   constexpr int KW = HALF ? kwaves_bf16(BM, BN) : kwaves(BM, BN);
   dim3 grid(tm * tn, splits), block(256 * KW);
+  const bool last = keep || splits == 1;      // no slab reduce follows
 #define CG_LAUNCH(TA, TB)                                                                    \
   do {                                                                                       \
     if (HALF) {                                                                              \
-      if (vec || AH || BH) hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, TA, TB, true, KW, AH, BH>), grid, block, 0, st, a);   \
-      else hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, TA, TB, false, KW, false, false>), grid, block, 0, st, a);            \
+      if (vec || AH || BH) CG_GEMM_LAUNCH(last, (gemm_bf16_kernel<BM, BN, TA, TB, true, KW, AH, BH>), grid, block, st, a);   \
+      else CG_GEMM_LAUNCH(last, (gemm_bf16_kernel<BM, BN, TA, TB, false, KW, false, false>), grid, block, st, a);            \
     } else {                                                                                 \
-      if (vec) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, true, KW>), grid, block, 0, st, a);    \
-      else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, false, KW>), grid, block, 0, st, a);       \
+      if (vec) CG_GEMM_LAUNCH(last, (gemm_f32_kernel<BM, BN, TA, TB, true, KW>), grid, block, st, a);    \
+      else CG_GEMM_LAUNCH(last, (gemm_f32_kernel<BM, BN, TA, TB, false, KW>), grid, block, st, a);       \
     }                                                                                        \
   } while (0)
   if (!transA && transB) CG_LAUNCH(false, true);
@@ -1124,10 +1175,11 @@ int launch_f32_dma(const GemmArgs& g, int transA, int transB, hipStream_t st, in
   splits = (nk + a.kt_per_split - 1) / a.kt_per_split;   // no empty split
   constexpr int KW = kwaves_dma(BM, BN), S = CG_DMA_STAGES;
   dim3 grid(tm * tn, splits), block(256 * KW);
-  if (!transA && transB) hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, false, true, KW, S>), grid, block, 0, st, a);
-  else if (!transA && !transB) hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, false, false, KW, S>), grid, block, 0, st, a);
-  else if (transA && !transB) hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, true, false, KW, S>), grid, block, 0, st, a);
-  else hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, true, true, KW, S>), grid, block, 0, st, a);
+  const bool last = keep || splits == 1;      // no slab reduce follows
+  if (!transA && transB) CG_GEMM_LAUNCH(last, (gemm_f32_dma_kernel<BM, BN, false, true, KW, S>), grid, block, st, a);
+  else if (!transA && !transB) CG_GEMM_LAUNCH(last, (gemm_f32_dma_kernel<BM, BN, false, false, KW, S>), grid, block, st, a);
+  else if (transA && !transB) CG_GEMM_LAUNCH(last, (gemm_f32_dma_kernel<BM, BN, true, false, KW, S>), grid, block, st, a);
+  else CG_GEMM_LAUNCH(last, (gemm_f32_dma_kernel<BM, BN, true, true, KW, S>), grid, block, st, a);
   if (keep) *keep = splits;
   else if (splits > 1) launch_splitk_reduce(g, splits, st);
   return cg_launch_status();
@@ -1138,6 +1190,7 @@ int gemm_dispatch(float* C, int ldc, const void* A, int lda, const void* B, int 
                   const float* bias, int epi, const float* E, int lde, float* aux, int ldaux,
                   float slope, int accumulate, void* workspace, size_t workspace_bytes, void* stream, int* keep,
                   void* c_bf16 = nullptr) {
+  timing_begin_call();
   if (!C || !A || !B || M < 0 || N < 0 || K < 0) return CG_ERR_BAD_ARG;
   if (c_bf16 && (keep || (uintptr_t)c_bf16 % 2)) return CG_ERR_BAD_ARG;
   if (M == 0 || N == 0) return CG_OK;
@@ -1285,4 +1338,45 @@ extern "C" int cg_gemm_slabs(float* C, int ldc, const void* A, int lda, const vo
   if (M == 0 || N == 0) return CG_OK;
   return gemm_dispatch(C, ldc, A, lda, B, ldb, M, N, K, transA, transB, dtype, bias, CG_EPI_NONE, nullptr, 0, nullptr, 0,
                        0.f, 0, workspace, workspace_bytes, stream, n_slabs);
+}
+
+extern "C" int cg_gemm_timing_begin(int max_calls) {
+  GemmTiming& t = tl_timing;
+  if (t.open || max_calls <= 0 || max_calls > (1 << 20)) return CG_ERR_BAD_ARG;
+  t.ev.assign(2 * (size_t)max_calls, nullptr);
+  t.state.assign((size_t)max_calls, 0);
+  for (auto& e : t.ev) {
+    hipError_t err = hipEventCreate(&e);
+    if (err != hipSuccess) {
+      for (auto& d : t.ev)
+        if (d) (void)hipEventDestroy(d);
+      t.ev.clear();
+      return (int)err;
+    }
+  }
+  t.calls = 0;
+  t.open = true;
+  return CG_OK;
+}
+
+extern "C" int cg_gemm_timing_end(float* ms, int capacity) {
+  GemmTiming& t = tl_timing;
+  if (!t.open || (capacity > 0 && !ms)) return CG_ERR_BAD_ARG;
+  t.open = false;
+  t.start = t.stop = nullptr;
+  hipError_t err = hipDeviceSynchronize();
+  const int n = (int)t.calls;
+  for (int i = 0; i < n && i < capacity; ++i) {
+    ms[i] = -1.f;       // a call that launched nothing, or whose events could not be read
+    if (t.state[i] == 3 && err == hipSuccess) {
+      float v = 0.f;
+      if (hipEventElapsedTime(&v, t.ev[2 * i], t.ev[2 * i + 1]) == hipSuccess) ms[i] = v;
+    }
+  }
+  for (auto& e : t.ev)
+    if (e) (void)hipEventDestroy(e);
+  t.ev.clear();
+  t.state.clear();
+  t.calls = 0;
+  return err == hipSuccess ? n : -(int)err - 100;
 }

@@ -405,16 +405,37 @@ class GenPass:
     def log_var(self):
         return self.ml[:self.b, self.L:]
 
+    def _dgrad_to_bn(self, d_prev, d, W):
+        """d_prev = d W, the gradient that the BatchNorm backward of the layer below reads next on this stream (nothing
+        else reads it).  When the product splits K its partial sums stay in the stream's scratch and that BatchNorm
+        adds them while it loads (`_slabs_for` tells it): one launch and one pass over the gradient less."""
+        ops = self.ops
+        ok = getattr(ops, "bn_bwd_slabs_ok", None)
+        keep = ok is not None and ok(*d_prev.shape) and not os.environ.get("CGRNA_NO_BWD_SLABS")
+        n = ops.gemm(d_prev, d, W, False, False, keep_slabs=True) if keep else ops.gemm(d_prev, d, W, False, False)
+        self._slabs_for = (d_prev.data_ptr(), n) if keep and n > 1 else None
+
+    _slabs_for = None
+
     def _bn_linear_bwd(self, d_act, d_h0, h0, act, stats, a_prev, lin, bn, d_prev, prev16=None):
         """Backward of Linear -> BatchNorm -> ReLU; d_prev (may be None) receives the input gradient."""
         ops, P, G = self.ops, self.net.P, self.net.G
-        ops.bn_bwd(d_h0, d_act, h0, act, None, stats[0], stats[1], P[bn + ".weight"], G[bn + ".weight"],
-                   G[bn + ".bias"], True, 0.0)
+        pending, self._slabs_for = self._slabs_for, None
+        if pending is not None and pending[0] == d_act.data_ptr():
+            ops.bn_bwd_slabs(d_h0, pending[1], h0, act, None, stats[0], stats[1], P[bn + ".weight"], G[bn + ".weight"],
+                             G[bn + ".bias"], True, 0.0)
+        else:
+            assert pending is None, "a product left its partial sums for a BatchNorm backward that did not follow"
+            ops.bn_bwd(d_h0, d_act, h0, act, None, stats[0], stats[1], P[bn + ".weight"], G[bn + ".weight"],
+                       G[bn + ".bias"], True, 0.0)
         kw = {} if prev16 is None else dict(b16=prev16)
         ops.gemm(G[lin + ".weight"], d_h0, a_prev, True, False, accumulate=True, **kw)
         # the Linear bias feeds a BatchNorm: its gradient is identically zero and is left at zero
         if d_prev is not None:
-            ops.gemm(d_prev, d_h0, P[lin + ".weight"], False, False)
+            if d_prev.data_ptr() in self._bn_inputs:
+                self._dgrad_to_bn(d_prev, d_h0, P[lin + ".weight"])
+            else:
+                ops.gemm(d_prev, d_h0, P[lin + ".weight"], False, False)
 
     def backward(self, d_out, need_dx=False, dx_out=None, dx_accumulate=False, kl=None, d_mu=None, d_lv=None,
                  hook=None):
@@ -445,7 +466,9 @@ class GenPass:
         last = f"decoder.{3 * nh}"
         ops.gemm(G[last + ".weight"], d, self.dec_a[nh - 1][:b], True, False, accumulate=True)
         ops.colsum(G[last + ".bias"], d, 1.0, True)
-        ops.gemm(self.d_act[nh - 1][:b], d, P[last + ".weight"], False, False)
+        # gradients that only a BatchNorm backward reads (d_act of every hidden layer; not the decoder input's)
+        self._bn_inputs = {self.d_act[li][:b].data_ptr() for li in range(nh)}
+        self._dgrad_to_bn(self.d_act[nh - 1][:b], d, P[last + ".weight"])
         for li in reversed(range(nh)):
             a_prev = self.dec_a[li - 1][:b] if li > 0 else self.dec_in[:b]
             d_prev = self.d_act[li - 1][:b] if li > 0 else self.d_dec_in[:b]
@@ -507,7 +530,8 @@ class GenPass:
         ops.gemm(self.GW_ml, dml, a_enc, True, False, accumulate=True)
         ops.colsum(self.Gb_ml, dml, 1.0, True)
         da = self.d_act[nh - 1][:b]
-        ops.gemm(da, dml, self.W_ml, False, False)
+        self._bn_inputs = {self.d_act[li][:b].data_ptr() for li in range(nh)}
+        self._dgrad_to_bn(da, dml, self.W_ml)
         dx = None
         for li in reversed(range(nh)):
             if li == 0 and hook is not None:

@@ -141,16 +141,23 @@ class HipOps:
         return True, ""
 
     # -- measurement: HIP events around every GEMM launch, on the launch stream ----------
-    def begin_gemm_timing(self):
+    def begin_gemm_timing(self, max_calls=1 << 14):
+        """From here to end_gemm_timing() every GEMM call's kernels carry a pair of HIP events attached to the
+        dispatches themselves (cg_gemm_timing_begin): start of the call's first kernel, end of its last one."""
+        _lib.check(self.lib.cg_gemm_timing_begin(max_calls), "cg_gemm_timing_begin")
         self._gemm_events = []
+        self._gemm_capacity = max_calls
 
     def end_gemm_timing(self):
         """Returns (launches, total milliseconds, executed FLOP, operand + result bytes) since begin_gemm_timing()."""
-        torch.cuda.synchronize(self.device)
         ev, self._gemm_events = self._gemm_events, None
-        self.last_gemm_detail = [(shape, a.elapsed_time(b), f) for a, b, f, _, shape in ev]
-        return (len(ev), sum(t for _, t, _ in self.last_gemm_detail), sum(f for _, _, f, _, _ in ev),
-                sum(by for _, _, _, by, _ in ev))
+        ms = (C.c_float * self._gemm_capacity)()
+        n = self.lib.cg_gemm_timing_end(ms, self._gemm_capacity)
+        if n != len(ev):
+            raise RuntimeError("cg_gemm_timing_end: %d calls recorded by the library, %d by the wrapper" % (n, len(ev)))
+        keep = [i for i, e in enumerate(ev) if ms[i] >= 0 and not e[3]]
+        self.last_gemm_detail = [(ev[i][2], float(ms[i]), ev[i][0]) for i in keep]
+        return (len(keep), sum(float(ms[i]) for i in keep), sum(ev[i][0] for i in keep), sum(ev[i][1] for i in keep))
 
     # -- plumbing -------------------------------------------------------------
     def _stream(self):
@@ -291,9 +298,6 @@ class HipOps:
             if sa is not None and sa % 8 == 0 and _ld(A) % 4 == 0 and A.shape[1] % 2 == 0 and \
                     (dtype & 2 or (B.data_ptr() % 16 == 0 and _ld(B) % 4 == 0)):
                 pA, dtype = C.c_void_p(sa), dtype | 4
-        if self._gemm_events is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(torch.cuda.current_stream(self.device))
         n_slabs = None
         if keep_slabs:
             assert epi == EPI_NONE and E is None and aux is None and not accumulate
@@ -307,22 +311,23 @@ class HipOps:
                                      dtype, _ptr(bias), epi, _ptr(E), _ld(E), _ptr(aux), _ld(aux), float(slope),
                                      int(accumulate), c16, _ptr(self._ws()[0]), self._ws()[0].numel() * 4,
                                      self._stream())
-        if self._gemm_events is not None:
-            e1.record(torch.cuda.current_stream(self.device))
+        if self._gemm_events is not None:       # the library has attached an event pair to this call's kernels
             elem = lambda flag: 2.0 if dtype & flag else 4.0  # noqa: E731
-            self._gemm_events.append((e0, e1, 2.0 * M * N * K,
+            self._gemm_events.append((2.0 * M * N * K,
                                       elem(4) * M * K + elem(2) * K * N + 4.0 * M * N * (2 if accumulate else 1),
-                                      (M, N, K, int(transA), int(transB), int(accumulate), dtype)))
+                                      (M, N, K, int(transA), int(transB), int(accumulate), dtype), self._gemm_skip))
         _lib.check(st, "cg_gemm")
         return n_slabs.value if n_slabs is not None else None
 
+    _gemm_skip = False
+
     def gemm_untimed(self, *args, **kw):
-        """gemm() without event bracketing even while begin_gemm_timing() is active."""
-        ev, self._gemm_events = self._gemm_events, None
+        """gemm() that end_gemm_timing() leaves out of its totals (filler work)."""
+        self._gemm_skip = True
         try:
             self.gemm(*args, **kw)
         finally:
-            self._gemm_events = ev
+            self._gemm_skip = False
 
     # -- BatchNorm --------------------------------------------------------------
     def bn_fwd(self, Y, X, gamma, beta, mean, invstd, rmean, rvar, slope, mask=None, pm=None, eps=1e-5,
@@ -402,6 +407,22 @@ class HipOps:
                                 int(accumulate), _ptr(gbar), _ptr(gxbar), float(slope), M, N, *self._twin(dX),
                                 *self._bnws(M, N), self._stream())
         _lib.check(st, "cg_bn_bwd")
+
+    def bn_bwd_slabs_ok(self, M, N):
+        """Can bn_bwd_slabs take an M x N gradient?  (Only the one-launch BatchNorm backward reads slabs.)"""
+        return bool(self.lib.cg_bn_bwd_slabs_ok(M, N))
+
+    def bn_bwd_slabs(self, dX, n_slabs, X, Y, PM, mean, invstd, gamma, dgamma, dbeta, accumulate, slope):
+        """bn_bwd whose incoming gradient is still in the n_slabs partial sums that gemm(..., keep_slabs=True) just
+        left in this stream's scratch."""
+        M, N = X.shape
+        assert dX.shape == X.shape
+        ws = self._ws()[0]
+        assert n_slabs >= 1 and n_slabs * M * N <= ws.numel()
+        st = self.lib.cg_bn_bwd_slabs(_ptr(dX), _ld(dX), _ptr(ws), n_slabs, _ptr(X), _ld(X), _ptr(Y), _ld(Y), _ptr(PM),
+                                      _ld(PM), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(dgamma), _ptr(dbeta),
+                                      int(accumulate), float(slope), M, N, *self._twin(dX), self._stream())
+        _lib.check(st, "cg_bn_bwd_slabs")
 
     def bn_bwd_bwd(self, Vu, Vh, dgamma, accumulate, W, U1, X, mean, invstd, gamma, ubar, mbar, PM=None):
         """PM: Vu is stored multiplied by it (see cg_bn_bwd_bwd)."""

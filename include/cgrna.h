@@ -214,6 +214,20 @@ int cg_bn_bwd_seg(float* dX, int lddx, const float* dY, int lddy, const float* X
                   void* dxbf16, int lddxbf16, void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * cg_bn_bwd whose incoming gradient dY is still in the n_slabs split-K partial sums that cg_gemm_slabs left in its
+ * workspace (dense M x N slabs, one after the other): the input-gradient product of the layer above
+ * (GAN_functions.py:89-94, 117-122 backward) and this BatchNorm backward then cost one pass over the gradient
+ * instead of a slab reduce plus a pass.  The slabs are added in slab order, so dX, dgamma and dbeta equal, bit for
+ * bit, what the slab reduce followed by cg_bn_bwd gives.  One-launch form only: cg_bn_bwd_slabs_ok(M, N) says
+ * whether the shape qualifies (one segment of at most 512 rows, at least 256 columns).
+ */
+int cg_bn_bwd_slabs_ok(int M, int N);
+int cg_bn_bwd_slabs(float* dX, int lddx, const float* slabs, int n_slabs, const float* X, int ldx,
+                    const float* Y, int ldy, const float* PM, int ldpm, const float* mean, const float* invstd,
+                    const float* gamma, float* dgamma, float* dbeta, int accumulate, float slope, int M, int N,
+                    void* dxbf16, int lddxbf16, void* stream);
+
+/*
  * BatchNorm backward-of-backward for the gradient penalty
  * (torch.autograd.grad(..., create_graph=True) then .backward(),
  * GAN_functions.py:199-203 through :166).  With u1 the first-order gradient
@@ -500,6 +514,17 @@ int cg_attn_bwd_blocks(int n_cells);
 long long cg_attn_bwd_ws(int n_cells, int E, int heads);
 int cg_attn_ln_bwd(float* dX, float* dparams, float* wpart, const float* dY, const float* X, const float* keep,
                    const float* params, int n_cells, int E, int heads, int accumulate, void* stream);
+
+/*
+ * Measurement aid; no counterpart in the reference.  Between cg_gemm_timing_begin(max_calls) and cg_gemm_timing_end
+ * every cg_gemm / cg_gemm_ex / cg_gemm_slabs call made by the calling thread (at most max_calls of them) carries a
+ * pair of HIP events attached to its own dispatches: the start of its first kernel and the end of its last one (the
+ * split-K slab reduce, when the call launches one).  cg_gemm_timing_end waits for the device, writes the elapsed
+ * milliseconds of the first `capacity` calls, in call order, to ms (-1 for a call that launched nothing), destroys
+ * the events and returns the number of calls recorded (negative on error).  Not for use during stream capture.
+ */
+int cg_gemm_timing_begin(int max_calls);
+int cg_gemm_timing_end(float* ms, int capacity);
 
 #ifdef __cplusplus
 }

@@ -723,6 +723,40 @@ def test_linear_batchnorm_with_slabs_left_to_the_consumer(ops, M, N, K, with_mas
     assert not ops.bn_slabs_ok(513, 512) and not ops.bn_slabs_ok(512, 128)
 
 
+@pytest.mark.parametrize("M,N,K", [(512, 1024, 512), (512, 512, 5000), (300, 256, 2048), (512, 2048, 1024), (37, 260, 4096)])
+def test_batchnorm_backward_with_slabs_left_to_the_consumer(ops, M, N, K):
+    """An input-gradient product whose split-K partial sums stay in the scratch + cg_bn_bwd_slabs (the BatchNorm
+    backward of the layer below adds them while it loads) against cg_gemm + cg_bn_bwd: the same additions in the same
+    order, so the input gradient and the parameter gradients are equal bit for bit."""
+    d, w = dev(rnd(M, K, seed=1)), dev(rnd(K, N, seed=2) * 0.05)
+    h0, gamma = dev(rnd(M, N, seed=3)), dev(rnd(N, seed=4).abs() + 0.5)
+    act = torch.relu(h0)
+    mean, var = h0.mean(0), h0.var(0, unbiased=False)
+    invstd = (var + 1e-5).rsqrt()
+    out = {}
+    for mode in ("plain", "slabs"):
+        dact, dh0 = torch.full((M, N), -3.0).cuda(), torch.empty(M, N).cuda()
+        dgamma, dbeta = dev(rnd(N, seed=5)), dev(rnd(N, seed=6))
+        if mode == "plain":
+            ops.gemm(dact, d, w, False, False)
+            ops.bn_bwd(dh0, dact, h0, act, None, mean, invstd, gamma, dgamma, dbeta, True, 0.0)
+            n = None
+        else:
+            assert ops.bn_bwd_slabs_ok(M, N)
+            n = ops.gemm(dact, d, w, False, False, keep_slabs=True)
+            if n > 1:
+                assert float(dact.min()) == -3.0 and float(dact.max()) == -3.0      # never written: only the consumer reads it
+                ops.bn_bwd_slabs(dh0, n, h0, act, None, mean, invstd, gamma, dgamma, dbeta, True, 0.0)
+            else:
+                ops.bn_bwd(dh0, dact, h0, act, None, mean, invstd, gamma, dgamma, dbeta, True, 0.0)
+        out[mode] = (dh0, dgamma, dbeta, n)
+    for a, b in zip(out["plain"][:3], out["slabs"][:3]):
+        assert torch.equal(a, b)
+    if K >= 1024 and M * N <= 512 * 1024:
+        assert out["slabs"][3] > 1, "expected this shape to split K (otherwise the test does not reach the slab path)"
+    assert not ops.bn_bwd_slabs_ok(513, 512) and not ops.bn_bwd_slabs_ok(512, 128)
+
+
 @pytest.mark.parametrize("M,N,G,E", [(512, 1024, 5000, 12), (37, 1024, 200, 12), (64, 256, 96, 0)])
 def test_first_layer_on_the_interpolates_by_linearity(ops, M, N, G, E):
     """cg_interp_hidden against the product it replaces: the first Linear on [alpha x_r + (1 - alpha) x_f | emb_f]
