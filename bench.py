@@ -339,10 +339,10 @@ def main():
                 print("%5d %5d %5d %2d %2d %3d %2d | %5.1f %10.1f %7.3f %6.1f" % (*shape, n / NB_CRITIC, ms / n * 1e3,
                       ms / NB_CRITIC, fl / ms / 1e9), file=sys.stderr)
         # What the counters say about the same kernels (rocprofv3 --pmc passes of this workload, separate runs;
-        # tools/profile_r02.sh writes the summaries): HBM bytes per launch and matrix-core busy share
+        # tools/profile_r03.sh writes the summaries): HBM bytes per launch and matrix-core busy share
         traffic, mfma = None, None
         tag = "bf16" if a.dtype == "bf16" else "f32"
-        pmc = _profile_json("r02_pmc_%s.json" % tag)
+        pmc = _profile_json("r03_pmc_%s.json" % tag) or _profile_json("r02_pmc_%s.json" % tag)
         if pmc and (G, B) == (G_GENES, BATCH):
             fam = [v for k, v in pmc["kernels"].items() if k.startswith("gemm")]
             if fam:

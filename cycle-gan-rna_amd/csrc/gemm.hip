@@ -1049,25 +1049,39 @@ __global__ void __launch_bounds__(256) gemm_small_n16_kernel(GemmArgs g, Strides
 }
 
 // M <= 2 with A stored [K][M] and B stored [K][N] (a weight gradient of the critic's one-column head: dval^T a3): a
-// workgroup owns 32 columns, its 32 row lanes stride over k, partial sums are added in lane order.
-__global__ void __launch_bounds__(1024) gemm_small_m_kernel(GemmArgs g) {
-  __shared__ float lds[2][32][33];
-  const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5, col = blockIdx.x * 32 + c;
+// workgroup owns 4 columns, its 64 k lanes stride over k (eight loads in flight per lane, unconditional: index
+// clamped, value discarded), partial sums are added in lane order.  (32 columns per workgroup and one load in flight
+// per lane took 14 us for 256 columns and K = 1024: eight workgroups, each a chain of 32 dependent load waits.)
+constexpr int SM_CW = 4, SM_KL = 64, SM_UN = 8;
+__global__ void __launch_bounds__(256) gemm_small_m_kernel(GemmArgs g) {
+  __shared__ float lds[2][SM_KL][SM_CW];
+  const int c = threadIdx.x % SM_CW, kl = threadIdx.x / SM_CW, col = blockIdx.x * SM_CW + c;
+  const int colc = min(col, g.N - 1);
   float acc[2] = {0.f, 0.f};
-  if (col < g.N)
-    for (int k = r0; k < g.K; k += 32) {
-      const float b = g.B[(size_t)k * g.ldb + col];
+  for (int k0 = kl; k0 < g.K; k0 += SM_KL * SM_UN) {
+    float b[SM_UN], a[SM_UN][2];
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
-        if (m < g.M) acc[m] += g.A[(size_t)k * g.lda + m] * b;
+    for (int u = 0; u < SM_UN; ++u) {
+      const int k = min(k0 + u * SM_KL, g.K - 1);
+      b[u] = g.B[(size_t)k * g.ldb + colc];
+      a[u][0] = g.A[(size_t)k * g.lda];
+      a[u][1] = g.A[(size_t)k * g.lda + (g.M > 1 ? 1 : 0)];
     }
-  lds[0][r0][c] = acc[0];
-  lds[1][r0][c] = acc[1];
+#pragma unroll
+    for (int u = 0; u < SM_UN; ++u) {
+      const float bv = k0 + u * SM_KL < g.K ? b[u] : 0.f;
+      acc[0] += a[u][0] * bv;
+      acc[1] += a[u][1] * bv;
+    }
+  }
+  lds[0][kl][c] = acc[0];
+  lds[1][kl][c] = acc[1];
   __syncthreads();
-  if (r0 < g.M && col < g.N) {
+  const int m = threadIdx.x / SM_CW;
+  if (m < g.M && col < g.N) {
     float h = g.bias ? g.bias[col] : 0.f;
-    for (int r = 0; r < 32; ++r) h += lds[r0][r][c];
-    epilogue_store(g, r0, col, h);
+    for (int r = 0; r < SM_KL; ++r) h += lds[m][r][c];
+    epilogue_store(g, m, col, h);
   }
 }
 
@@ -1081,7 +1095,7 @@ bool launch_small(const GemmArgs& g, int transA, int transB, hipStream_t st) {
     return true;
   }
   if (g.M <= 2 && transA && !transB) {
-    CG_GEMM_LAUNCH(true, gemm_small_m_kernel, dim3((g.N + 31) / 32), dim3(1024), st, g);
+    CG_GEMM_LAUNCH(true, gemm_small_m_kernel, dim3((g.N + SM_CW - 1) / SM_CW), dim3(SM_CW * SM_KL), st, g);
     return true;
   }
   // a few columns: every wave reads B once per row it owns, which stays cheap while B is a few vectors (measured:

@@ -1,4 +1,4 @@
-"""Summarise the rocprofv3 passes of tools/profile_r02.sh for one mode (f32 | bf16) into one JSON:
+"""Summarise the rocprofv3 passes of tools/profile_r03.sh for one mode (f32 | bf16) into one JSON:
 
   kernels      per kernel family: launches in the counter run, mean FETCH_SIZE / WRITE_SIZE (KB), corrected HBM bytes
                per launch (FETCH_SIZE x 2: gfx950 counts 64 B per 128-B request of wide coalesced reads; WRITE_SIZE is
@@ -10,7 +10,7 @@
                kernel cycles = GRBM_GUI_ACTIVE / 8 (the counter sums the 8 XCDs), summed over all launches of the run;
                MFMA operations issued; share of wave time parked in s_waitcnt / barriers
 
-    python tools/profile_summary_r02.py gpurun_out/r02 f32 profiles/r02_pmc_f32.json
+    python tools/profile_summary.py gpurun_out/r02 f32 profiles/r02_pmc_f32.json
 """
 import collections
 import csv

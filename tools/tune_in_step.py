@@ -30,6 +30,7 @@ THRESH = 0.97          # a candidate must beat the current choice by 3 % (--thre
 for _a in sys.argv[1:]:
     if _a.startswith("--thresh="):
         THRESH = float(_a.split("=", 1)[1])
+DUMP = "--dump" in sys.argv[1:]         # print the time of every candidate, not only the winners
 dev = torch.device("cuda", 0)
 cfg = S.default_config(preprocess_type="log_normalized", batch_size=B)
 nets = S.random_networks(G, G, [12], cfg, seed=0)
@@ -77,6 +78,8 @@ for shape in shapes:
         for sp in (1, 2, 3, 4, 6, 8, 12, 16):
             os.environ["CGRNA_GEMM_OVERRIDE"] = f"{M},{N},{K},{ta},{tb},{acc},{t},{sp}"
             us = measure(1)[shape][0]
+            if DUMP:
+                print(f"# cand {M},{N},{K},{ta},{tb},{acc} tile {t} splits {sp}: {us:.2f} us", flush=True)
             if us < best[0]:
                 best = (us, (t, sp))
     os.environ.pop("CGRNA_GEMM_OVERRIDE", None)
