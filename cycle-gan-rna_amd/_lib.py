@@ -1,4 +1,10 @@
-"""ctypes binding of libcgrna.so (the C ABI declared in include/cgrna.h).
+"""Binding of libcgrna.so (the C ABI declared in include/cgrna.h).
+
+load() returns the thin PyTorch-ROCm C++ extension built over the C ABI (lib/_cgrna_torch*.so, generated from the
+signature table below by build.py): one function per entry point, pointers passed as integers
+(tensor.data_ptr()), and a stream argument that is either a hipStream_t handle or -(device index + 1) for "the
+current HIP stream of that device", looked up in C++.  load_ctypes() binds the same library with ctypes (plain C ABI,
+used by tests that call an entry point directly and by the export check).
 
 torch must be imported before the library is loaded so that both share one HIP
 runtime (the library's libamdhip64.so.7 dependency then resolves to the copy
@@ -79,7 +85,7 @@ SIGNATURES = {
     "cg_poisson_bwd": ([P, I, P, I, P, I, P, I, F, I, I, I, P], I),
     "cg_centroid_bwd": ([P, I, P, I, P, I, P, I, P, I, F, I, I, I, I, P], I),
     "cg_fm_bwd": ([P, I, P, P, P, I, F, I, I, I, P], I),
-    "cg_gloss_finalize": ([P, P, P, P, P, C.POINTER(GlossDesc), P], I),
+    "cg_gloss_finalize": ([P, P, P, P, P, P, P], I),
     "cg_sum_parts": ([P, P, P, P, P, I, P], I),
     "cg_adam_amsgrad": ([P, P, P, P, P, Z, P, F, F, F, P, P], I),
     "cg_attn_ln_fwd": ([P, P, P, P, I, I, I, P], I),
@@ -87,29 +93,56 @@ SIGNATURES = {
     "cg_attn_bwd_ws": ([I, I, I], C.c_longlong),
     "cg_attn_ln_bwd": ([P, P, P, P, P, P, P, I, I, I, I, P], I),
     "cg_gemm_timing_begin": ([I], I),
-    "cg_gemm_timing_end": ([C.POINTER(C.c_float), I], I),
+    "cg_gemm_timing_end": ([P, I], I),
 }
 
 _lib = None
+_ext = None
 
 
-def load():
-    """Returns the loaded library with argtypes set; raises if it is absent."""
+def _missing(path):
+    return RuntimeError(f"{path} is missing: build it with `python cycle-gan-rna_amd/build.py` "
+                        "(this package has no CPU or PyTorch fallback for its kernels)")
+
+
+def load_ctypes():
+    """The library bound with ctypes, argtypes set; raises if it is absent."""
     global _lib
     if _lib is not None:
         return _lib
     path = os.environ.get("CGRNA_LIB", LIB_PATH)     # tuning aid: a differently built copy of the same library
     if not os.path.exists(path):
-        raise RuntimeError(
-            f"{path} is missing: build it with `python cycle-gan-rna_amd/build.py` "
-            "(this package has no CPU or PyTorch fallback for its kernels)")
-    lib = C.CDLL(path)
+        raise _missing(path)
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
     for name, (argtypes, restype) in SIGNATURES.items():
         fn = getattr(lib, name)      # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
         fn.restype = restype
     _lib = lib
     return lib
+
+
+def load():
+    """The C++ extension over the C ABI (see the module docstring); raises if it or the library is absent."""
+    global _ext
+    if _ext is not None:
+        return _ext
+    if os.environ.get("CGRNA_LIB"):      # a differently built copy of the library: the ctypes binding can take it
+        return load_ctypes()
+    if not os.path.exists(LIB_PATH):
+        raise _missing(LIB_PATH)
+    import glob
+    import importlib.util
+    found = glob.glob(os.path.join(_HERE, "lib", "_cgrna_torch*.so"))
+    if not found:
+        raise _missing(os.path.join(_HERE, "lib", "_cgrna_torch*.so"))
+    spec = importlib.util.spec_from_file_location("_cgrna_torch", found[0])
+    ext = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ext)
+    for name in SIGNATURES:
+        getattr(ext, name)               # AttributeError if the extension is older than the table
+    _ext = ext
+    return ext
 
 
 class CgError(RuntimeError):

@@ -29,7 +29,8 @@ def attn_nparam(E):
 
 
 def _ptr(t):
-    return C.c_void_p(t.data_ptr()) if t is not None else None
+    """Device address as an integer (0 for None)."""
+    return t.data_ptr() if t is not None else 0
 
 
 def _ld(t):
@@ -63,6 +64,8 @@ class HipOps:
             raise RuntimeError("cycle-gan-rna_amd needs a HIP device (torch.cuda.is_available() is False)")
         self.lib = _lib.load()
         self.device = torch.device(device if device is not None else "cuda:0")
+        self._stream_token = -((self.device.index or 0) + 1)
+        self._ext = not isinstance(self.lib, C.CDLL)
         self._gemm_events = None
         # scratch shared by the kernels that need one (split-K partials, BatchNorm chunk sums); kernels on
         # one stream run in order, so one buffer per use serves every call
@@ -117,7 +120,7 @@ class HipOps:
                                    "once eagerly at this size first" % need)
             self._retired_scratch.append(ws[1])
             ws[1] = torch.empty(need // 8 + 1, dtype=torch.float64, device=self.device)
-        return C.c_void_p(ws[1].data_ptr()), ws[1].numel() * 8
+        return ws[1].data_ptr(), ws[1].numel() * 8
 
     # -- hardware queues and forked HIP graphs --------------------------------------
     @staticmethod
@@ -152,7 +155,7 @@ class HipOps:
         """Returns (launches, total milliseconds, executed FLOP, operand + result bytes) since begin_gemm_timing()."""
         ev, self._gemm_events = self._gemm_events, None
         ms = (C.c_float * self._gemm_capacity)()
-        n = self.lib.cg_gemm_timing_end(ms, self._gemm_capacity)
+        n = self.lib.cg_gemm_timing_end(C.addressof(ms), self._gemm_capacity)
         if n != len(ev):
             raise RuntimeError("cg_gemm_timing_end: %d calls recorded by the library, %d by the wrapper" % (n, len(ev)))
         keep = [i for i, e in enumerate(ev) if ms[i] >= 0 and not e[3]]
@@ -161,7 +164,11 @@ class HipOps:
 
     # -- plumbing -------------------------------------------------------------
     def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        # "the current HIP stream of this device", resolved inside the extension (c10::hip::getCurrentHIPStream);
+        # the ctypes binding (a differently built library, CGRNA_LIB) is handed the handle itself
+        if self._ext:
+            return self._stream_token
+        return torch.cuda.current_stream(self.device).cuda_stream
 
     def empty(self, *shape, dtype=torch.float32):
         return torch.empty(*shape, dtype=dtype, device=self.device)
@@ -221,7 +228,7 @@ class HipOps:
     def copy(self, out, x):
         """out <- x (2-D), keeping the bf16 image of `out` up to date when it has one."""
         c16, _ = self._twin(out)
-        if c16 is None:
+        if not c16:
             out.copy_(x)
             return
         M, N = out.shape
@@ -231,7 +238,7 @@ class HipOps:
     def zero(self, out):
         """out <- 0 (2-D), keeping the bf16 image of `out` up to date when it has one."""
         c16, _ = self._twin(out)
-        if c16 is None:
+        if not c16:
             out.zero_()
             return
         M, N = out.shape
@@ -260,11 +267,11 @@ class HipOps:
 
     def _twin(self, t):
         """(address of the bf16 image of the output view `t`, its leading dimension) for a kernel's bf16-output
-        argument; (None, 0) when `t` has no image."""
+        argument; (0, 0) when `t` has no image."""
         if not self._shadows:
-            return None, 0
+            return 0, 0
         sp = self._shadow_ptr(t)
-        return (C.c_void_p(sp), _ld(t)) if sp is not None else (None, 0)
+        return (sp, _ld(t)) if sp is not None else (0, 0)
 
     # -- GEMM -----------------------------------------------------------------
     def gemm(self, Cm, A, B, transA=False, transB=False, bias=None, epi=EPI_NONE, E=None, aux=None, slope=0.0,
@@ -294,17 +301,17 @@ class HipOps:
             sb = b16 if b16 is not None else self._shadow_ptr(B)
             if sb is not None and sb % 8 == 0 and _ld(B) % 4 == 0 and B.shape[1] % 2 == 0 and \
                     (A.data_ptr() % 16 == 0 and _ld(A) % 4 == 0):
-                pB, dtype = C.c_void_p(sb), dtype | 2
+                pB, dtype = sb, dtype | 2
             if sa is not None and sa % 8 == 0 and _ld(A) % 4 == 0 and A.shape[1] % 2 == 0 and \
                     (dtype & 2 or (B.data_ptr() % 16 == 0 and _ld(B) % 4 == 0)):
-                pA, dtype = C.c_void_p(sa), dtype | 4
+                pA, dtype = sa, dtype | 4
         n_slabs = None
         if keep_slabs:
             assert epi == EPI_NONE and E is None and aux is None and not accumulate
             n_slabs = C.c_int(1)
             st = self.lib.cg_gemm_slabs(_ptr(Cm), _ld(Cm), pA, _ld(A), pB, _ld(B), M, N, K, int(transA), int(transB),
                                         dtype, _ptr(bias), _ptr(self._ws()[0]), self._ws()[0].numel() * 4,
-                                        C.byref(n_slabs), self._stream())
+                                        C.addressof(n_slabs), self._stream())
         else:
             c16, _ = self._twin(Cm)
             st = self.lib.cg_gemm_ex(_ptr(Cm), _ld(Cm), pA, _ld(A), pB, _ld(B), M, N, K, int(transA), int(transB),
@@ -381,7 +388,7 @@ class HipOps:
         assert mean.numel() >= nseg * N and invstd.numel() >= nseg * N
         st = self.lib.cg_bn_bwd_seg(_ptr(dX), _ld(dX), _ptr(dY), _ld(dY), _ptr(X), _ld(X), _ptr(Y), _ld(Y), _ptr(PM),
                                     _ld(PM), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(dgamma), _ptr(dbeta),
-                                    int(accumulate), None, None, float(slope), M // nseg, nseg, N, *self._twin(dX),
+                                    int(accumulate), 0, 0, float(slope), M // nseg, nseg, N, *self._twin(dX),
                                     *self._bnws(M // nseg, N, nseg), self._stream())
         _lib.check(st, "cg_bn_bwd_seg")
 
@@ -557,7 +564,7 @@ class HipOps:
     # `red` = (parts [n_slots, MAX_PARTS] float32, nparts [n_slots] int32); slot picks the row.
     def _slot(self, red, slot):
         parts, nparts = red
-        return (C.c_void_p(parts.data_ptr() + slot * MAX_PARTS * 4), C.c_void_p(nparts.data_ptr() + slot * 4))
+        return (parts.data_ptr() + slot * MAX_PARTS * 4, nparts.data_ptr() + slot * 4)
 
     def reduce_sum(self, red, slot, X):
         X2 = X if X.dim() == 2 else X.view(1, -1)
@@ -649,7 +656,7 @@ class HipOps:
         assert w is None or (w.dtype == torch.float32 and w.numel() == 5 and w.is_contiguous())
         d.weights = _ptr(w)
         assert ema.dtype == torch.float64 and losses.dtype == torch.float64 and losses.numel() >= 12 and coef.numel() >= 6
-        st = self.lib.cg_gloss_finalize(_ptr(ema), _ptr(losses), _ptr(coef), _ptr(parts), _ptr(nparts), C.byref(d),
+        st = self.lib.cg_gloss_finalize(_ptr(ema), _ptr(losses), _ptr(coef), _ptr(parts), _ptr(nparts), C.addressof(d),
                                         self._stream())
         _lib.check(st, "cg_gloss_finalize")
 

@@ -23,7 +23,9 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} is declared in cgrna.h but not exported"
     assert set(_lib.SIGNATURES) == names, set(_lib.SIGNATURES) ^ names
-    assert _lib.load().cg_version() >= 100
+    assert _lib.load_ctypes().cg_version() >= 100
+    ext = _lib.load()               # the torch C++ extension over the same C ABI: one function per entry point
+    assert all(hasattr(ext, n) for n in names) and ext.cg_version() == _lib.load_ctypes().cg_version()
 
 
 def test_every_entry_point_cites_the_reference():

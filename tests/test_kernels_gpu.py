@@ -93,7 +93,7 @@ def test_gemm_bf16_operands_stored_as_bf16(ops, M, N, K, ta, tb, lda_pad, ldb_pa
     same result, bit for bit, as the float32 copy of the same (bf16-representable) values rounded while staged."""
     import ctypes as C
     from cycle_gan_rna_amd import _lib
-    lib = _lib.load()
+    lib = _lib.load_ctypes()
     ar, ac = (K, M) if ta else (M, K)
     br, bc = (N, K) if tb else (K, N)
     A = rnd(ar, ac + lda_pad, seed=1).bfloat16().float()

@@ -38,7 +38,7 @@ def _run(lib, static, M, N, seed):
 
 def test_static_scratch_entry_point_matches_workspace_entry_point():
     from cycle_gan_rna_amd import _lib
-    lib = _lib.load()
+    lib = _lib.load_ctypes()
     # both shapes take the two-launch form that uses the scratch (more than 512 rows, or fewer than 256 columns);
     # the second call is smaller, so stale sums of the first stay in the array beside the fresh ones
     for M, N, seed in ((2048, 1000, 1), (640, 200, 2)):
