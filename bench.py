@@ -156,6 +156,45 @@ def api_loop(dev, G, B, epochs=(2, 12)):
                      f"of {epochs[1]} epochs minus wall time of {epochs[0]} epochs over the {iters} extra iterations")
 
 
+def big_shard(dev, genes=20000, batch=BATCH, steps=20):
+    """One GPU's share of the largest named configuration (about 20 000 ortholog genes, batch 4096 over 8 GPUs = 512
+    cells per GPU): the same step, float32, HIP graphs + side streams + lookahead, on one device."""
+    from cycle_gan_rna_amd.engine import StepEngine
+    from cycle_gan_rna_amd.noise import DeviceNoise
+    from cycle_gan_rna_amd.ops import HipOps
+    from cycle_gan_rna_amd import synthetic as S
+    cfg = S.default_config(preprocess_type="log_normalized", batch_size=batch)
+    nets = S.random_networks(genes, genes, [N_TYPES], cfg, seed=0)
+    xm, lm = S.synthetic_expression(4 * batch, genes, N_TYPES, seed=1234, device=dev)
+    xh, lh = S.synthetic_expression(4 * batch, genes, N_TYPES, seed=1235, device=dev)
+    eng = StepEngine(nets, cfg, S.centroid_table(xm, lm, N_TYPES), S.centroid_table(xh, lh, N_TYPES), HipOps(dev), batch)
+    lm, lh = lm[:, None].contiguous(), lh[:, None].contiguous()
+    noise = DeviceNoise(dev, seed=1, default_generator=True)
+    eng.enable_concurrency()
+    eng.enable_graphs()
+    eng.enable_lookahead()
+
+    def b(i):
+        s = (i % 4) * batch
+        return xm[s:s + batch], xh[s:s + batch], lm[s:s + batch], lh[s:s + batch]
+    for i in range(2 * NB_CRITIC + 2 + 4):
+        noise.begin_step()
+        eng.iteration(i, *b(i), noise, nxt=b(i + 1), metrics=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        noise.begin_step()
+        eng.iteration(i, *b(i), noise, nxt=b(i + 1), metrics=False)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    losses = {**eng.d_losses(), **eng.g_losses()}
+    assert all(v == v and abs(v) < 1e30 for v in losses.values() if isinstance(v, float)), losses
+    eng.close()
+    return dict(genes=genes, batch_per_gpu=batch, dtype="f32", steps=steps, ms_per_step=dt / steps * 1e3,
+                value=batch * steps / dt, unit="cells/s",
+                gflop_per_iteration=algorithmic_gflop_per_cell_iteration(genes) * batch)
+
+
 def _profile_json(name):
     path = os.path.join(ROOT, "profiles", name)
     return json.load(open(path)) if os.path.exists(path) else None
@@ -174,6 +213,7 @@ def main():
                     help="f32: exact float32 MFMA everywhere; bf16: large dense-layer products on the bf16 MFMA")
     ap.add_argument("--no-bf16-line", action="store_true", help="skip the secondary bf16-MFMA measurement of an f32 run")
     ap.add_argument("--no-api-loop", action="store_true", help="skip the measurement through train_enhanced_cycle_gan")
+    ap.add_argument("--no-big-shard", action="store_true", help="skip the 20 000-gene line (one GPU's share of the largest configuration)")
     ap.add_argument("--sequential", action="store_true", help="one stream instead of two")
     ap.add_argument("--no-lookahead", action="store_true",
                     help="do not issue the generators' forward passes ahead of the previous critic work")
@@ -314,21 +354,26 @@ def main():
     eng.flush()                        # several ranks: apply the critic update that is still in flight
     if not a.no_roofline and rank == 0:
         eng.sync.enabled = False       # only this rank runs the pass below, so it must not issue collectives
-        # GEMM launches of NB_CRITIC iterations (4 critic + 1 generator step), launched one by one (no graph replay)
-        # and each bracketed by HIP events on the launch stream.  A block of filler work is queued first so that the
-        # host runs ahead of the GPU and the event pairs time the kernels, not the gaps between launches.
+        # GEMM launches of NB_CRITIC iterations (4 critic + 1 generator step), launched one by one (no graph replay),
+        # each call's kernels carrying a pair of HIP events attached to the dispatches themselves on the launch
+        # stream.  A block of filler work is queued first so that the host runs ahead of the GPU.
         eng.use_graphs = False
         eng.lookahead = False
         eng.concurrent = False         # one stream: every launch is timed with the chip to itself
         filler_a = torch.rand(4096, 4096, device=dev)
         filler_c = torch.empty(4096, 4096, device=dev)
-        ops.begin_gemm_timing()
-        for i in range(NB_CRITIC):
-            for _ in range(24):
-                ops.gemm_untimed(filler_c, filler_a, filler_a, False, True)
-            step(i)
-        torch.cuda.synchronize()
-        n_launch, gemm_ms, exec_flop, gemm_bytes = ops.end_gemm_timing()
+        # three repeats of NB_CRITIC iterations; the repeat with the smallest GEMM time is reported (every repeat's
+        # total is listed in "gemm_ms_per_iteration_repeats"): one repeat is 342 launches in 10 ms of device time
+        repeats = []
+        for _ in range(3):
+            ops.begin_gemm_timing()
+            for i in range(NB_CRITIC):
+                for _ in range(24):
+                    ops.gemm_untimed(filler_c, filler_a, filler_a, False, True)
+                step(i)
+            torch.cuda.synchronize()
+            repeats.append((ops.end_gemm_timing(), ops.last_gemm_detail))
+        (n_launch, gemm_ms, exec_flop, gemm_bytes), ops.last_gemm_detail = min(repeats, key=lambda r: r[0][1])
         if a.gemm_shapes:
             agg = {}
             for shape, ms, fl in ops.last_gemm_detail:
@@ -362,6 +407,9 @@ def main():
                     operand_bytes_per_launch=gemm_bytes / n_launch,
                     kernel=kname, launches_per_iteration=n_launch / NB_CRITIC,
                     avg_launch_us=gemm_ms * 1e3 / n_launch, gemm_ms_per_iteration=gemm_ms / NB_CRITIC,
+                    gemm_ms_per_iteration_repeats=[r[0][1] / NB_CRITIC for r in repeats],
+                    timing="HIP events attached to the dispatches (cg_gemm_timing_begin/_end): start of a call's "
+                           "first kernel to the end of its last one, split-K slab reduce included",
                     algorithmic_tflops=alg_flop / (gemm_ms * 1e-3) / 1e12, mfma_counters=mfma,
                     hbm_kernels=(pmc or {}).get("hbm_kernels"))
     if world > 1:
@@ -404,9 +452,15 @@ def main():
         other = dict(dtype="bf16", value=B * world * a.steps / dt16, unit="cells/s", ms_per_step=dt16 / a.steps * 1e3,
                      note="same step, dense-layer products with M,N>=128, K>=256 on v_mfma_f32_16x16x32_bf16")
     api = None
-    if world == 1 and not a.only and not a.no_api_loop and a.dtype == "f32" and not a.eager and not a.sequential:
+    if world == 1 and not one_rank_group and not a.only and not a.no_api_loop and a.dtype == "f32" and not a.eager \
+            and not a.sequential:
         eng.close()
         api = api_loop(dev, G, B)
+    big = None
+    if world == 1 and not one_rank_group and not a.only and not a.no_big_shard and a.dtype == "f32" and not a.eager \
+            and not a.sequential \
+            and (G, B) == (G_GENES, BATCH):
+        big = big_shard(dev)
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline()
@@ -420,7 +474,7 @@ def main():
                                    f"expression, {'bf16 MFMA for the large layers' if a.dtype == 'bf16' else 'float32 MFMA'}", "global_batch": B * world,
                        "parallelism": f"dp{world}"},
             "roofline": roof, "cpu_baseline": cpu, "bf16_mfma": other, "step_parts": parts,
-            "api_loop": api,
+            "api_loop": api, "shard_of_20k_gene_config": big,
         }
         sys.stdout.flush()
         os.dup2(json_fd, 1)

@@ -11,11 +11,11 @@ echo "bench done"
 cd /tmp && export TMPDIR=/tmp
 for mode in f32 bf16; do
   rm -rf $O/ks_$mode $O/pf_$mode $O/pw_$mode $O/pm_$mode
-  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/ks_$mode -o ks --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-roofline --no-bf16-line --no-api-loop --steps 20 --warmup 4 --eager --sequential --dtype $mode > $O/ks_$mode.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/ks_$mode -o ks --output-format csv -- python3 $R/bench.py --no-cpu-baseline --no-roofline --no-bf16-line --no-api-loop --no-big-shard --steps 20 --warmup 4 --eager --sequential --dtype $mode > $O/ks_$mode.log 2>&1
   echo "stats $mode done"
-  timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pf_$mode -o pf --output-format csv -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --no-bf16-line --no-api-loop --eager --sequential --dtype $mode > $O/pf_$mode.log 2>&1
-  timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pw_$mode -o pw --output-format csv -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --no-bf16-line --no-api-loop --eager --sequential --dtype $mode > $O/pw_$mode.log 2>&1
-  timeout -s KILL 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace -d $O/pm_$mode -o pm --output-format csv -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --no-bf16-line --no-api-loop --eager --sequential --dtype $mode > $O/pm_$mode.log 2>&1
+  timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pf_$mode -o pf --output-format csv -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --no-bf16-line --no-api-loop --no-big-shard --eager --sequential --dtype $mode > $O/pf_$mode.log 2>&1
+  timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pw_$mode -o pw --output-format csv -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --no-bf16-line --no-api-loop --no-big-shard --eager --sequential --dtype $mode > $O/pw_$mode.log 2>&1
+  timeout -s KILL 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --kernel-trace -d $O/pm_$mode -o pm --output-format csv -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-roofline --no-bf16-line --no-api-loop --no-big-shard --eager --sequential --dtype $mode > $O/pm_$mode.log 2>&1
   echo "pmc $mode done"
   python3 $R/tools/kernel_stats_summary.py $O/ks_$mode 24 $O/${mode}_sequential_kernel_stats.csv > /dev/null
   python3 $R/tools/profile_summary.py $O $mode $O/pmc_$mode.json > /dev/null
