@@ -101,7 +101,7 @@ struct GemmArgs {
   int epi, accumulate;
   float slope;
   int tiles_n;
-  int kt_per_split;   // K slabs handled by one blockIdx.y (split-K); all of them when gridDim.y == 1
+  int kt_per_split;   // K slabs handled by one split (split-K; see xcd_tile_split); all of them when gridDim.y == 1
   float* ws;          // split-K: partial results [gridDim.y][M][N]
   unsigned a_bytes, b_bytes;   // footprints of A and B in memory (hardware range check of the buffer loads)
   u16* C16;           // optional bf16 image of C (same leading dimension): every value stored to C is also stored here
@@ -213,9 +213,19 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, int row, int c
 
 // XCD-aware tile index: workgroups are dealt round-robin over the 8 XCDs; give each XCD a contiguous run of
 // tiles (neighbours share an A row panel and adjacent B panels) so panel re-reads hit that XCD's L2.  Bijective.
-__device__ __forceinline__ int xcd_tile() {
-  const int nwg = gridDim.x, q = nwg >> 3, rem = nwg & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-  return (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+// Workgroup -> (output tile, K split).  Workgroups are handed to the eight XCDs round-robin in dispatch order
+// (x fastest, then y).  Each XCD gets a contiguous run of the (split, tile) pairs, split-major: with S splits an XCD
+// works on 1/8 of the pairs, i.e. on one split's K range (or a few) for a compact patch of tiles, so what its L2
+// requests from the fabric is that K range of the operand panels only - not the whole K extent of every panel its
+// tiles touch, as when all splits of a tile share an XCD.  Which split a partial sum belongs to (its slab) does not
+// depend on where it was computed, so results are unchanged.
+__device__ __forceinline__ void xcd_tile_split(int& tile, int& split) {
+  const int tiles = gridDim.x, nwg = tiles * gridDim.y;
+  const int lin = blockIdx.x + tiles * blockIdx.y;
+  const int q = nwg >> 3, rem = nwg & 7, xcd = lin & 7, idx = lin >> 3;
+  const int p = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + idx;
+  split = p / tiles;
+  tile = p - split * tiles;
 }
 
 // Tile index -> (tile row, tile column).  Within an XCD's contiguous run the tiles are walked column-first inside
@@ -380,7 +390,8 @@ __global__ void __launch_bounds__(256 * KW) gemm_bf16_kernel(GemmArgs g) {
   constexpr int A_ELEMS = lds_elems<BM, A_MMAJ>(), B_ELEMS = lds_elems<BN, B_MMAJ>();
   __shared__ __align__(16) u16 smem[2 * (A_ELEMS + B_ELEMS)];
 
-  const int tile = xcd_tile();
+  int tile, split;
+  xcd_tile_split(tile, split);
   int tile_m, tile_n;
   tile_coords(tile, (g.M + BM - 1) / BM, g.tiles_n, tile_m, tile_n);
   const int bm = tile_m * BM, bn = tile_n * BN;
@@ -402,7 +413,7 @@ __global__ void __launch_bounds__(256 * KW) gemm_bf16_kernel(GemmArgs g) {
   typename StagerSel<BM, A_MMAJ, VEC, NT, AH>::type sa[D];
   typename StagerSel<BN, B_MMAJ, VEC, NT, BH>::type sb[D];
   const int nk_all = (g.K + BKH - 1) / BKH;
-  const int kt0 = blockIdx.y * g.kt_per_split;
+  const int kt0 = split * g.kt_per_split;
   const int nk = min(nk_all, kt0 + g.kt_per_split);
 
   const int klim = min(g.K, nk * BKH);   // straight-line loop body, see gemm_f32_kernel
@@ -472,7 +483,7 @@ __global__ void __launch_bounds__(256 * KW) gemm_bf16_kernel(GemmArgs g) {
   }
 
   // 16x16 accumulator: col = lane & 15, row = 4 * (lane >> 4) + reg
-  float* wsp = gridDim.y > 1 ? g.ws + (size_t)blockIdx.y * g.M * g.N : nullptr;
+  float* wsp = gridDim.y > 1 ? g.ws + (size_t)split * g.M * g.N : nullptr;
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -495,7 +506,7 @@ __global__ void __launch_bounds__(256 * KW) gemm_bf16_kernel(GemmArgs g) {
 // split's slab or the epilogue is applied.  32x32 accumulator: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 template <int TM, int TN, int KW>
 __device__ __forceinline__ void finish_f32(const GemmArgs& g, f32x16 (&acc)[TM][TN], float* smem, int bm, int bn, int wm,
-                                           int wn, int lane, int wave, int kg) {
+                                           int wn, int lane, int wave, int kg, int split) {
   const int li = lane & 31, lh = lane >> 5;
   if (KW > 1) {
     float* xs = smem + ((kg > 0 ? kg - 1 : 0) * 4 + wave) * (TM * TN * 16 * 64) + lane;
@@ -520,7 +531,7 @@ __device__ __forceinline__ void finish_f32(const GemmArgs& g, f32x16 (&acc)[TM][
             acc[i][j][r] += xs[(q - 1) * 4 * (TM * TN * 16 * 64) + ((i * TN + j) * 16 + r) * 64];
   }
   if (gridDim.y > 1) {   // split-K: raw partial sums, combined by splitk_reduce_kernel or by the consumer
-    float* wsp = g.ws + (size_t)blockIdx.y * g.M * g.N;
+    float* wsp = g.ws + (size_t)split * g.M * g.N;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -563,7 +574,8 @@ __global__ void __launch_bounds__(256 * KW) gemm_f32_kernel(GemmArgs g) {
   constexpr int B_ELEMS = B_MMAJ ? BK * (BN + 4) : BN * (BK + 4);
   __shared__ __align__(16) float smem[2 * (A_ELEMS + B_ELEMS)];
 
-  const int tile = xcd_tile();
+  int tile, split;
+  xcd_tile_split(tile, split);
   int tile_m, tile_n;
   tile_coords(tile, (g.M + BM - 1) / BM, g.tiles_n, tile_m, tile_n);
   const int bm = tile_m * BM, bn = tile_n * BN;
@@ -590,7 +602,7 @@ __global__ void __launch_bounds__(256 * KW) gemm_f32_kernel(GemmArgs g) {
   Stager<BM, A_MMAJ, VEC, NT> sa[D];
   Stager<BN, B_MMAJ, VEC, NT> sb[D];
   const int nk_all = (g.K + BK - 1) / BK;
-  const int kt0 = blockIdx.y * g.kt_per_split;
+  const int kt0 = split * g.kt_per_split;
   const int nk = min(nk_all, kt0 + g.kt_per_split);
 
   // The loop body is straight-line: every load, LDS store and barrier is unconditional, so the compiler can count
@@ -656,7 +668,7 @@ __global__ void __launch_bounds__(256 * KW) gemm_f32_kernel(GemmArgs g) {
     }
   }
 
-  finish_f32<TM, TN, KW>(g, acc, smem, bm, bn, wm, wn, lane, wave, kg);
+  finish_f32<TM, TN, KW>(g, acc, smem, bm, bn, wm, wn, lane, wave, kg, split);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -735,12 +747,13 @@ __global__ void __launch_bounds__(256 * KW) gemm_f32_dma_kernel(GemmArgs g) {
   static_assert(KW == 1 || TM * TN * 16 * 256 * (KW - 1) <= S * STAGE, "accumulator exchange does not fit in LDS");
   __shared__ __align__(16) float smem[S * STAGE];      // the kernel's only LDS object
 
-  const int tile = xcd_tile();
+  int tile, split;
+  xcd_tile_split(tile, split);
   int tile_m, tile_n;
   tile_coords(tile, (g.M + BM - 1) / BM, g.tiles_n, tile_m, tile_n);
   const int bm = tile_m * BM, bn = tile_n * BN;
   const int nk_all = (g.K + BK - 1) / BK;
-  const int kt0 = blockIdx.y * g.kt_per_split;
+  const int kt0 = split * g.kt_per_split;
   const int nk = min(nk_all, kt0 + g.kt_per_split);
   const int nslab = nk - kt0;
   typedef DmaTile<BM, A_MMAJ, NC> TileA;
@@ -861,7 +874,7 @@ __global__ void __launch_bounds__(256 * KW) gemm_f32_dma_kernel(GemmArgs g) {
   wait_vmcnt<0>();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  finish_f32<TM, TN, KW>(g, acc, smem, bm, bn, wm, wn, lane, wave, kg);
+  finish_f32<TM, TN, KW>(g, acc, smem, bm, bn, wm, wn, lane, wave, kg, split);
 }
 
 // Combine the split-K partials in split order and apply the epilogue of cg_gemm.  VEC4: four consecutive columns
