@@ -211,8 +211,6 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& g, int row, int c
   if (g.C16) g.C16[(size_t)row * g.ldc + col] = f2bf(out);
 }
 
-// XCD-aware tile index: workgroups are dealt round-robin over the 8 XCDs; give each XCD a contiguous run of
-// tiles (neighbours share an A row panel and adjacent B panels) so panel re-reads hit that XCD's L2.  Bijective.
 // Workgroup -> (output tile, K split).  Workgroups are handed to the eight XCDs round-robin in dispatch order
 // (x fastest, then y).  Each XCD gets a contiguous run of the (split, tile) pairs, split-major: with S splits an XCD
 // works on 1/8 of the pairs, i.e. on one split's K range (or a few) for a compact patch of tiles, so what its L2

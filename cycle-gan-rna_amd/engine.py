@@ -731,6 +731,7 @@ class CriticStack:
         self.demb = Z((nx + 1) * B, self.E)
         self.zero_emb = Z(B, max(self.E, 1))
         self.demb_diff = Z(B, max(self.E, 1))
+        self._lsum = {}
         self.alpha = None                       # the interpolation weights of the current critic step (forward)
         self._dval_const = {}
         self.rowpen = Z(B)
@@ -835,21 +836,50 @@ class CriticStack:
         workspaces.  The embedding columns of the interpolates are the generated batch's, not interpolated: there
         the product misses (a vh0)^T (emb_f - emb_r), added by a second, 12-column product.  Call after
         backward_params() and gp_backward() of the same step; written (first touch) to the gradient arena."""
-        ops, G, Gd = self.ops, self.net.G, self.Gd
+        ops, G, P, Gd = self.ops, self.net.G, self.net.P, self.Gd
         assert self.gp_layout and self.alpha is not None
         av, de = self.h1024a[:b], self.demb_diff[:b]
         labels = self.have_labels and self.E > 0
-        if labels:
+        tables = _emb_tables(G) if labels else []
+        # The embedding columns of the first layer, by label sums.  The tables' gradient is
+        # sum over rows of label t of ([dh0_r; dh0_f; u0; vh0] W1[:, G:])[m] = (sum of those rows) W1[:, G:] - the rows of
+        # u0 carry the label -1 (no cell) and drop out - and the correction product (a vh0)^T (emb_f - emb_r) is
+        # (sum of a vh0 by generated label - sum by real label)^T table: two passes over hidden gradients and two
+        # products with a dozen rows instead of two products with thousands of rows and a scatter.
+        by_label = labels and hasattr(ops, "label_colsum") and not os.environ.get("CGRNA_NO_LABEL_SUMS") and \
+            all(G[k].shape[0] <= ops.LABEL_COLSUM_MAX_TYPES for k, _ in tables)
+        if by_label:
+            off = Gd
+            for i, (k, w) in enumerate(tables):
+                S = self._label_sums(k)
+                ops.label_colsum(S, self.g1024b[:4 * b], self.lab[:4 * b, i:i + 1])
+                ops.gemm(G[k], S, P["model.0.weight"][:, off:off + w], False, False, accumulate=True)
+                off += w
+        elif labels:
             # the embedding tables' gradient of both chains in one product and one scatter over all four row blocks:
-            # [dh0_r; dh0_f; u0; vh0] W1[:, G:] summed per cell type - the rows of u0 carry the label -1 (no cell) and
-            # drop out
-            ops.gemm(self.demb[:4 * b], self.g1024b[:4 * b], self.net.P["model.0.weight"][:, Gd:], False, False)
+            # [dh0_r; dh0_f; u0; vh0] W1[:, G:] summed per cell type
+            ops.gemm(self.demb[:4 * b], self.g1024b[:4 * b], P["model.0.weight"][:, Gd:], False, False)
             _embed_scatter(ops, G, self.demb[:4 * b], self.lab[:4 * b], True)
+        plain = labels and not by_label
         ops.gp_combine(self.g1024b[:2 * b], self.g1024b[3 * b:4 * b], self.alpha, av,
-                       self.emb[:2 * b] if labels else None, de if labels else None)
+                       self.emb[:2 * b] if plain else None, de if plain else None)
         ops.gemm(G["model.0.weight"], self.g1024b[:3 * b], self.xe[:3 * b, :self.W], True, False)
-        if labels:
+        if by_label:
+            off = Gd
+            for i, (k, w) in enumerate(tables):
+                T = self._label_sums(k)
+                ops.label_colsum(T, av, self.lab[b:2 * b, i:i + 1])
+                ops.label_colsum(T, av, self.lab[:b, i:i + 1], scale=-1.0, accumulate=True)
+                ops.gemm(G["model.0.weight"][:, off:off + w], T, P[k], True, False, accumulate=True)
+                off += w
+        elif labels:
             ops.gemm(G["model.0.weight"][:, Gd:self.W], av, de, True, False, accumulate=True)
+
+    def _label_sums(self, key):
+        """(types of the table `key`) x 1024 workspace for sums of hidden gradients by label."""
+        if key not in self._lsum:
+            self._lsum[key] = self.ops.zeros(self.net.G[key].shape[0], 1024)
+        return self._lsum[key]
 
     def backward_input(self, b, coef, idx, scale, dfeat, dx_out):
         """Generator step (nx = nseg - 1): gradient w.r.t. the first input batch of

@@ -478,6 +478,17 @@ class HipOps:
                                        n_types, int(accumulate), self._stream())
         _lib.check(st, "cg_embed_scatter")
 
+    LABEL_COLSUM_MAX_TYPES = 32
+
+    def label_colsum(self, out, X, labels, scale=1.0, accumulate=False):
+        """out[t] (+)= scale * sum of the rows of X whose label is t (labels (M, 1) or (M,) int64; others skipped)."""
+        n_types, N = out.shape
+        M = X.shape[0]
+        assert X.shape[1] == N and labels.shape[0] == M and out.is_contiguous() and labels.dtype == torch.int64
+        st = self.lib.cg_label_colsum(_ptr(out), _ptr(X), _ld(X), _ptr(labels), labels.stride(0), M, N, n_types,
+                                      float(scale), int(accumulate), self._stream())
+        _lib.check(st, "cg_label_colsum")
+
     def reparam_fwd(self, z, ml, eps):
         M, L = z.shape
         assert ml.shape == (M, 2 * L) and eps.shape == (M, L) and eps.is_contiguous()

@@ -266,6 +266,16 @@ int cg_copy_bf16(float* out, void* out_bf16, int ldo, const float* x, int ldx, i
  * out_bf16 (may be NULL): bf16 image of `out`, same leading dimension. */
 int cg_embed_gather(float* out, int ldo, const float* table, int E, const int64_t* labels, int lstride,
                     int M, int n_types, void* out_bf16, void* stream);
+/*
+ * Sums of the rows of X (M x N) by label: out[t, n] (+)= scale * sum over rows m with labels[m*lstride] == t of
+ * X[m, n], out dense (n_types x N); rows with a label outside [0, n_types) are skipped; deterministic order;
+ * n_types <= 32.  The gradient of an embedding table that enters a Linear layer beside the data
+ * (GAN_functions.py:161-165,181-184) is  sum over rows with label t of (dh W_e)[m]  =  (sum over those rows of
+ * dh[m]) W_e:  summing the hidden gradients by label first turns a rows x E x hidden product and a scatter into
+ * this pass and an n_types x E x hidden product.
+ */
+int cg_label_colsum(float* out, const float* X, int ldx, const int64_t* labels, int lstride, int M, int N,
+                    int n_types, float scale, int accumulate, void* stream);
 /* Its gradient: dtable[t, e] (+)= sum over rows with label t of dout[m, e] (deterministic order). */
 int cg_embed_scatter(float* dtable, int E, const float* dout, int lddo, const int64_t* labels, int lstride,
                      int M, int n_types, int accumulate, void* stream);

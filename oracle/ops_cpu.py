@@ -255,6 +255,16 @@ class CpuOps:
         acc.index_add_(0, lab[keep], dout.contiguous()[keep])
         dtable.copy_(dtable + acc if accumulate else acc)
 
+    LABEL_COLSUM_MAX_TYPES = 32
+
+    def label_colsum(self, out, X, labels, scale=1.0, accumulate=False):
+        """cg_label_colsum: out[t] (+)= scale * sum of the rows of X with label t; other labels are skipped."""
+        lab = labels.reshape(labels.shape[0], -1)[:, 0]
+        keep = (lab >= 0) & (lab < out.shape[0])
+        acc = torch.zeros_like(out)
+        acc.index_add_(0, lab[keep], X.contiguous()[keep])
+        out.copy_((out if accumulate else 0) + scale * acc)
+
     def reparam_fwd(self, z, ml, eps):
         L = z.shape[1]
         z.copy_(ml[:, :L] + eps * torch.exp(0.5 * ml[:, L:]))

@@ -864,3 +864,27 @@ def test_batchnorm_kernels_keep_bf16_images(M, N, nseg):
             Y.zero_()
             ops16.bn_fwd_slabs(Y, H, n, bias, gamma, beta, mean[0], invstd[0], rm, rv, 0.0)
             assert torch.equal(_image(ops16, Y), Y.bfloat16()) and float(Y.abs().max()) > 0
+
+
+@pytest.mark.parametrize("M,N,T", [(2048, 1024, 12), (512, 1024, 12), (37, 50, 3), (1000, 1024, 32)])
+def test_label_colsum(ops, M, N, T):
+    """cg_label_colsum: sums of rows by label (labels outside the table are skipped), with scale and accumulation,
+    against the CPU restatement; twice the same bits (no atomics)."""
+    x = rnd(M, N + 8, seed=1)[:, :N]
+    lab = torch.randint(-1, T, (M, 1), generator=torch.Generator().manual_seed(2))
+    base = rnd(T, N, seed=3)
+    exp = base.clone()
+    cpu.label_colsum(exp, x.double().float(), lab, scale=-0.5, accumulate=True)
+    xd, ld = dev(x), lab.cuda()
+    outs = []
+    for _ in range(2):
+        out = dev(base.clone())
+        ops.label_colsum(out, xd, ld, scale=-0.5, accumulate=True)
+        outs.append(out.cpu())
+    assert torch.equal(outs[0], outs[1])
+    close(outs[0], exp, 1e-5)
+    plain = torch.full((T, N), 7.0).cuda()
+    ops.label_colsum(plain, xd, ld)
+    exp2 = torch.zeros(T, N)
+    cpu.label_colsum(exp2, x, lab)
+    close(plain, exp2, 1e-5)
