@@ -105,6 +105,8 @@ struct GemmArgs {
   float* ws;          // split-K: partial results [gridDim.y][M][N]
   unsigned a_bytes, b_bytes;   // footprints of A and B in memory (hardware range check of the buffer loads)
   u16* C16;           // optional bf16 image of C (same leading dimension): every value stored to C is also stored here
+  unsigned* counters; // split-K combined inside the kernel (see split_tail): one arrival counter per output tile, else nullptr
+  int vec4;           // the combining pass may use 16-byte accesses (see reduce_vec4)
 };
 
 #ifndef CG_BK
@@ -379,6 +381,111 @@ __device__ __forceinline__ bf16x8 fragment(const u16* s, int row0, int kbase, in
   return u.f;
 }
 
+// One output element (VEC4: four consecutive columns, 16-byte accesses) from the split-K partial sums: the bias, then
+// the slabs in split order, then the epilogue of cg_gemm.
+template <bool VEC4, bool SC1 = false>
+__device__ __forceinline__ void combine_slabs(const GemmArgs& g, int splits, int m, int n) {
+  constexpr int W = VEC4 ? 4 : 1;
+  const size_t e0 = (size_t)m * g.N + n;
+  float h[W];
+#pragma unroll
+  for (int e = 0; e < W; ++e) h[e] = g.bias ? g.bias[n + e] : 0.f;
+  for (int k = 0; k < splits; ++k) {
+    const float* p = g.ws + (size_t)k * g.M * g.N + e0;
+    if (VEC4) {
+      // SC1: slabs stored write-through by other workgroups of this launch are read past this CU's L1
+      const f32x4 v = SC1 ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                make_rsrc(g.ws, 0xfffffff0u), (unsigned)(((size_t)k * g.M * g.N + e0) * 4), 0, 16))
+                          : *reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+      for (int e = 0; e < W; ++e) h[e] += v[e];
+    } else {
+      h[0] += SC1 ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p[0];
+    }
+  }
+  float* cp = g.C + (size_t)m * g.ldc + n;
+  float out[W], pmv[W];
+  if (g.epi == CG_EPI_NONE) {
+    if (g.accumulate) {
+      if (VEC4) {
+        const f32x4 c = *reinterpret_cast<const f32x4*>(cp);
+#pragma unroll
+        for (int e = 0; e < W; ++e) out[e] = c[e] + h[e];
+      } else {
+        out[0] = cp[0] + h[0];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < W; ++e) out[e] = h[e];
+    }
+  } else {
+    float ev[W];
+    if (g.E) {
+      const float* ep = g.E + (size_t)m * g.lde + n;
+      if (VEC4) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(ep);
+#pragma unroll
+        for (int e = 0; e < W; ++e) ev[e] = t[e];
+      } else {
+        ev[0] = ep[0];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < W; ++e) ev[e] = 1.f;
+    }
+#pragma unroll
+    for (int e = 0; e < W; ++e) {
+      pmv[e] = g.epi == CG_EPI_LEAKY ? (h[e] > 0.f ? 1.f : g.slope) * ev[e] : ev[e];
+      out[e] = h[e] * pmv[e];
+    }
+    if (g.epi == CG_EPI_LEAKY && g.aux) {
+      float* ap = g.aux + (size_t)m * g.ldaux + n;
+      if (VEC4) *reinterpret_cast<f32x4*>(ap) = f32x4{pmv[0], pmv[W > 1 ? 1 : 0], pmv[W > 2 ? 2 : 0], pmv[W > 3 ? 3 : 0]};
+      else ap[0] = pmv[0];
+    }
+  }
+  if (VEC4) *reinterpret_cast<f32x4*>(cp) = f32x4{out[0], out[W > 1 ? 1 : 0], out[W > 2 ? 2 : 0], out[W > 3 ? 3 : 0]};
+  else cp[0] = out[0];
+  if (g.C16) {
+    u16* hp = g.C16 + (size_t)m * g.ldc + n;
+    if (VEC4) *reinterpret_cast<uint2*>(hp) = pack4(out[0], out[W > 1 ? 1 : 0], out[W > 2 ? 2 : 0], out[W > 3 ? 3 : 0]);
+    else hp[0] = f2bf(out[0]);
+  }
+}
+
+// Split-K without a second launch (GemmArgs::counters): every workgroup, having written its slab, makes its stores
+// visible to the whole device (release fence) and one of its threads adds 1 to the arrival counter of the output
+// tile.  The workgroup that finds gridDim.y - 1 there is the last of its tile: behind an acquire fence it combines
+// the tile's slabs in split order - the additions of splitk_reduce_kernel in the same order, whichever workgroup
+// happens to arrive last - and puts the counter back to 0 for the next product that uses it.  No workgroup ever
+// waits for another.  Every thread of the workgroup must call this (two barriers); `flag`: one int of LDS that
+// nothing else uses any more.
+template <int BM, int BN, int NT>
+__device__ __forceinline__ void split_tail(const GemmArgs& g, int tile, int bm, int bn, int* flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's write-through slab stores have been acknowledged
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned arrived = __hip_atomic_fetch_add(g.counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = arrived == gridDim.y - 1;
+    if (last) __hip_atomic_exchange(g.counters + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *flag = last;
+  }
+  __syncthreads();
+  if (!*flag) return;
+  const int splits = gridDim.y;
+  if (g.vec4) {
+    for (int i = threadIdx.x; i < BM * BN / 4; i += NT) {
+      const int m = bm + i / (BN / 4), n = bn + 4 * (i % (BN / 4));
+      if (m < g.M && n < g.N) combine_slabs<true, true>(g, splits, m, n);
+    }
+  } else {
+    for (int i = threadIdx.x; i < BM * BN; i += NT) {
+      const int m = bm + i / BN, n = bn + i % BN;
+      if (m < g.M && n < g.N) combine_slabs<false, true>(g, splits, m, n);
+    }
+  }
+}
+
 // AH / BH: the operand is stored as bf16 (see StagerB16), otherwise as float32 and rounded while staged.
 template <int BM, int BN, bool TA, bool TB, bool VEC, int KW, bool AH, bool BH>
 __global__ void __launch_bounds__(256 * KW) gemm_bf16_kernel(GemmArgs g) {
@@ -457,6 +564,7 @@ __global__ void __launch_bounds__(256 * KW) gemm_bf16_kernel(GemmArgs g) {
     }
   }
 
+  const bool fused = gridDim.y > 1 && g.counters != nullptr;   // split-K combined by the last workgroup of each tile
   if (KW > 1) {   // add the wave groups' accumulators through LDS (the K loop ended on a barrier)
     float* xs = reinterpret_cast<float*>(smem) + ((kg > 0 ? kg - 1 : 0) * 4 + wave) * (TM * TN * 4 * 64) + lane;
     if (kg > 0) {
@@ -468,35 +576,41 @@ __global__ void __launch_bounds__(256 * KW) gemm_bf16_kernel(GemmArgs g) {
           for (int r = 0; r < 4; ++r) xs[((i * TN + j) * 4 + r) * 64] = acc[i][j][r];
     }
     __syncthreads();
-    if (kg > 0) return;
+    if (kg > 0 && !fused) return;
+    if (kg == 0) {
 #pragma unroll
-    for (int q = 1; q < KW; ++q)
+      for (int q = 1; q < KW; ++q)
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+          for (int j = 0; j < TN; ++j)
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            acc[i][j][r] += xs[(q - 1) * 4 * (TM * TN * 4 * 64) + ((i * TN + j) * 4 + r) * 64];
+            for (int r = 0; r < 4; ++r)
+              acc[i][j][r] += xs[(q - 1) * 4 * (TM * TN * 4 * 64) + ((i * TN + j) * 4 + r) * 64];
+    }
   }
 
   // 16x16 accumulator: col = lane & 15, row = 4 * (lane >> 4) + reg
   float* wsp = gridDim.y > 1 ? g.ws + (size_t)split * g.M * g.N : nullptr;
+  if (kg == 0) {
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = bn + wn + 16 * j + lr;
-      if (col >= g.N) continue;
-      const float bv = (g.bias && !wsp) ? g.bias[col] : 0.f;
+      for (int j = 0; j < TN; ++j) {
+        const int col = bn + wn + 16 * j + lr;
+        if (col >= g.N) continue;
+        const float bv = (g.bias && !wsp) ? g.bias[col] : 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = bm + wm + 16 * i + 4 * lg + r;
-        if (row >= g.M) continue;
-        if (wsp) wsp[(size_t)row * g.N + col] = acc[i][j][r];
-        else epilogue_store(g, row, col, acc[i][j][r] + bv);
+        for (int r = 0; r < 4; ++r) {
+          const int row = bm + wm + 16 * i + 4 * lg + r;
+          if (row >= g.M) continue;
+          if (wsp && fused) __hip_atomic_store(wsp + (size_t)row * g.N + col, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else if (wsp) wsp[(size_t)row * g.N + col] = acc[i][j][r];
+          else epilogue_store(g, row, col, acc[i][j][r] + bv);
+        }
       }
-    }
+  }
+  if (fused) split_tail<BM, BN, NT>(g, tile, bm, bn, reinterpret_cast<int*>(smem));
 }
 
 // Tail of the float32 kernels: the wave groups' accumulators are added through LDS in group order (the caller's K
@@ -504,8 +618,9 @@ __global__ void __launch_bounds__(256 * KW) gemm_bf16_kernel(GemmArgs g) {
 // split's slab or the epilogue is applied.  32x32 accumulator: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
 template <int TM, int TN, int KW>
 __device__ __forceinline__ void finish_f32(const GemmArgs& g, f32x16 (&acc)[TM][TN], float* smem, int bm, int bn, int wm,
-                                           int wn, int lane, int wave, int kg, int split) {
+                                           int wn, int lane, int wave, int kg, int split, int tile) {
   const int li = lane & 31, lh = lane >> 5;
+  const bool fused = gridDim.y > 1 && g.counters != nullptr;   // split-K combined by the last workgroup of each tile
   if (KW > 1) {
     float* xs = smem + ((kg > 0 ? kg - 1 : 0) * 4 + wave) * (TM * TN * 16 * 64) + lane;
     if (kg > 0) {
@@ -517,31 +632,65 @@ __device__ __forceinline__ void finish_f32(const GemmArgs& g, f32x16 (&acc)[TM][
           for (int r = 0; r < 16; ++r) xs[((i * TN + j) * 16 + r) * 64] = acc[i][j][r];
     }
     __syncthreads();
-    if (kg > 0) return;
+    if (kg > 0 && !fused) return;
+    if (kg == 0) {
 #pragma unroll
-    for (int q = 1; q < KW; ++q)
+      for (int q = 1; q < KW; ++q)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              acc[i][j][r] += xs[(q - 1) * 4 * (TM * TN * 16 * 64) + ((i * TN + j) * 16 + r) * 64];
+    }
+  }
+  if (fused && g.vec4) {
+    // slab stores that other workgroups read in this launch are write-through, and a write-through store of 4 bytes
+    // is a fabric write of its own: the tile goes through LDS and leaves as 16-byte pieces of rows
+    constexpr int BM = 64 * TM, BN = 64 * TN, LDT = BN + 4, NT = 256 * KW;
+    __syncthreads();      // the accumulator exchange has been read
+    if (kg == 0) {
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
           for (int r = 0; r < 16; ++r)
-            acc[i][j][r] += xs[(q - 1) * 4 * (TM * TN * 16 * 64) + ((i * TN + j) * 16 + r) * 64];
+            smem[(wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDT + wn + 32 * j + li] = acc[i][j][r];
+    }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(g.ws, 0xfffffff0u);
+    const size_t slab = (size_t)split * g.M * g.N;
+    for (int idx = threadIdx.x; idx < BM * BN / 4; idx += NT) {
+      const int r = idx / (BN / 4), c = 4 * (idx % (BN / 4)), row = bm + r, col = bn + c;
+      if (row < g.M && col < g.N)
+        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(smem + r * LDT + c), rs,
+                                               (unsigned)((slab + (size_t)row * g.N + col) * 4), 0, 16);   // 16: sc1
+    }
+    split_tail<BM, BN, NT>(g, tile, bm, bn, reinterpret_cast<int*>(smem));
+    return;
   }
-  if (gridDim.y > 1) {   // split-K: raw partial sums, combined by splitk_reduce_kernel or by the consumer
-    float* wsp = g.ws + (size_t)split * g.M * g.N;
+  if (gridDim.y > 1) {   // split-K: raw partial sums, combined by split_tail, splitk_reduce_kernel or the consumer
+    if (kg == 0) {
+      float* wsp = g.ws + (size_t)split * g.M * g.N;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int col = bn + wn + 32 * j + li;
-        if (col >= g.N) continue;
+        for (int j = 0; j < TN; ++j) {
+          const int col = bn + wn + 32 * j + li;
+          if (col >= g.N) continue;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = bm + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (row < g.M) wsp[(size_t)row * g.N + col] = acc[i][j][r];
+          for (int r = 0; r < 16; ++r) {
+            const int row = bm + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (row < g.M) {
+              if (fused) __hip_atomic_store(wsp + (size_t)row * g.N + col, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              else wsp[(size_t)row * g.N + col] = acc[i][j][r];
+            }
+          }
         }
-      }
+    }
+    if (fused) split_tail<64 * TM, 64 * TN, 256 * KW>(g, tile, bm, bn, reinterpret_cast<int*>(smem));
     return;
   }
 #pragma unroll
@@ -666,7 +815,7 @@ __global__ void __launch_bounds__(256 * KW) gemm_f32_kernel(GemmArgs g) {
     }
   }
 
-  finish_f32<TM, TN, KW>(g, acc, smem, bm, bn, wm, wn, lane, wave, kg, split);
+  finish_f32<TM, TN, KW>(g, acc, smem, bm, bn, wm, wn, lane, wave, kg, split, tile);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -872,7 +1021,7 @@ __global__ void __launch_bounds__(256 * KW) gemm_f32_dma_kernel(GemmArgs g) {
   wait_vmcnt<0>();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  finish_f32<TM, TN, KW>(g, acc, smem, bm, bn, wm, wn, lane, wave, kg, split);
+  finish_f32<TM, TN, KW>(g, acc, smem, bm, bn, wm, wn, lane, wave, kg, split, tile);
 }
 
 // Combine the split-K partials in split order and apply the epilogue of cg_gemm.  VEC4: four consecutive columns
@@ -883,68 +1032,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(GemmArgs g, int spli
   const size_t total = (size_t)g.M * g.N / W;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     const size_t e0 = i * W;
-    const int m = (int)(e0 / g.N), n = (int)(e0 % g.N);
-    float h[W];
-#pragma unroll
-    for (int e = 0; e < W; ++e) h[e] = g.bias ? g.bias[n + e] : 0.f;
-    for (int k = 0; k < splits; ++k) {
-      const float* p = g.ws + (size_t)k * g.M * g.N + e0;
-      if (VEC4) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(p);
-#pragma unroll
-        for (int e = 0; e < W; ++e) h[e] += v[e];
-      } else {
-        h[0] += p[0];
-      }
-    }
-    float* cp = g.C + (size_t)m * g.ldc + n;
-    float out[W], pmv[W];
-    if (g.epi == CG_EPI_NONE) {
-      if (g.accumulate) {
-        if (VEC4) {
-          const f32x4 c = *reinterpret_cast<const f32x4*>(cp);
-#pragma unroll
-          for (int e = 0; e < W; ++e) out[e] = c[e] + h[e];
-        } else {
-          out[0] = cp[0] + h[0];
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < W; ++e) out[e] = h[e];
-      }
-    } else {
-      float ev[W];
-      if (g.E) {
-        const float* ep = g.E + (size_t)m * g.lde + n;
-        if (VEC4) {
-          const f32x4 t = *reinterpret_cast<const f32x4*>(ep);
-#pragma unroll
-          for (int e = 0; e < W; ++e) ev[e] = t[e];
-        } else {
-          ev[0] = ep[0];
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < W; ++e) ev[e] = 1.f;
-      }
-#pragma unroll
-      for (int e = 0; e < W; ++e) {
-        pmv[e] = g.epi == CG_EPI_LEAKY ? (h[e] > 0.f ? 1.f : g.slope) * ev[e] : ev[e];
-        out[e] = h[e] * pmv[e];
-      }
-      if (g.epi == CG_EPI_LEAKY && g.aux) {
-        float* ap = g.aux + (size_t)m * g.ldaux + n;
-        if (VEC4) *reinterpret_cast<f32x4*>(ap) = f32x4{pmv[0], pmv[W > 1 ? 1 : 0], pmv[W > 2 ? 2 : 0], pmv[W > 3 ? 3 : 0]};
-        else ap[0] = pmv[0];
-      }
-    }
-    if (VEC4) *reinterpret_cast<f32x4*>(cp) = f32x4{out[0], out[W > 1 ? 1 : 0], out[W > 2 ? 2 : 0], out[W > 3 ? 3 : 0]};
-    else cp[0] = out[0];
-    if (g.C16) {
-      u16* hp = g.C16 + (size_t)m * g.ldc + n;
-      if (VEC4) *reinterpret_cast<uint2*>(hp) = pack4(out[0], out[W > 1 ? 1 : 0], out[W > 2 ? 2 : 0], out[W > 3 ? 3 : 0]);
-      else hp[0] = f2bf(out[0]);
-    }
+    combine_slabs<VEC4>(g, splits, (int)(e0 / g.N), (int)(e0 % g.N));
   }
 }
 
@@ -1124,11 +1212,26 @@ bool launch_small(const GemmArgs& g, int transA, int transB, hipStream_t st) {
   return false;
 }
 
+// May the pass that combines split-K slabs use 16-byte accesses?
+bool reduce_vec4(const GemmArgs& g) {
+  auto al = [](const void* p, int ld) { return p == nullptr || (((uintptr_t)p % 16 == 0) && ld % 4 == 0); };
+  return g.N % 4 == 0 && al(g.C, g.ldc) && al(g.E, g.lde) && al(g.aux, g.ldaux) && al(g.ws, 4) && (uintptr_t)g.C16 % 8 == 0;
+}
+
+// Tile arrival counters at the end of a workspace handed in with CG_WS_TILE_COUNTERS, and whether a product of
+// `tiles` output tiles combines its `splits` slabs itself (split_tail) instead of by a second launch.
+constexpr size_t WS_COUNTER_BYTES = 16384;
+bool fuse_split_tail(GemmArgs& a, long tiles, int splits, const int* keep) {
+  static const bool separate = getenv("CGRNA_GEMM_SEPARATE_REDUCE") != nullptr;     // A/B aid
+  const bool fuse = !keep && splits > 1 && a.counters && !separate && tiles <= (long)(WS_COUNTER_BYTES / sizeof(unsigned));
+  if (!fuse) a.counters = nullptr;
+  a.vec4 = reduce_vec4(a);
+  return fuse;
+}
+
 void launch_splitk_reduce(const GemmArgs& g, int splits, hipStream_t st) {
   const size_t total = (size_t)g.M * g.N;
-  auto al = [](const void* p, int ld) { return p == nullptr || (((uintptr_t)p % 16 == 0) && ld % 4 == 0); };
-  const bool v4 = g.N % 4 == 0 && al(g.C, g.ldc) && al(g.E, g.lde) && al(g.aux, g.ldaux) && al(g.ws, 4) &&
-                  (uintptr_t)g.C16 % 8 == 0;
+  const bool v4 = reduce_vec4(g);
   int blocks = (int)((total / (v4 ? 4 : 1) + 255) / 256);
   if (blocks > 2048) blocks = 2048;
   if (v4) CG_GEMM_LAUNCH(true, splitk_reduce_kernel<true>, dim3(blocks), dim3(256), st, g, splits);
@@ -1147,7 +1250,8 @@ int launch_f32(const GemmArgs& g, int transA, int transB, bool vec, hipStream_t 
   splits = (nk + a.kt_per_split - 1) / a.kt_per_split;   // no empty split
   constexpr int KW = HALF ? kwaves_bf16(BM, BN) : kwaves(BM, BN);
   dim3 grid(tm * tn, splits), block(256 * KW);
-  const bool last = keep || splits == 1;      // no slab reduce follows
+  const bool fused = fuse_split_tail(a, (long)tm * tn, splits, keep);
+  const bool last = keep || splits == 1 || fused;      // no slab reduce follows
 #define CG_LAUNCH(TA, TB)                                                                    \
   do {                                                                                       \
     if (HALF) {                                                                              \
@@ -1164,7 +1268,7 @@ int launch_f32(const GemmArgs& g, int transA, int transB, bool vec, hipStream_t 
   else CG_LAUNCH(true, true);
 #undef CG_LAUNCH
   if (keep) *keep = splits;
-  else if (splits > 1) launch_splitk_reduce(g, splits, st);
+  else if (splits > 1 && !fused) launch_splitk_reduce(g, splits, st);
   return cg_launch_status();
 }
 
@@ -1200,13 +1304,14 @@ int launch_f32_dma(const GemmArgs& g, int transA, int transB, hipStream_t st, in
   splits = (nk + a.kt_per_split - 1) / a.kt_per_split;   // no empty split
   constexpr int KW = kwaves_dma(BM, BN), S = CG_DMA_STAGES;
   dim3 grid(tm * tn, splits), block(256 * KW);
-  const bool last = keep || splits == 1;      // no slab reduce follows
+  const bool fused = fuse_split_tail(a, (long)tm * tn, splits, keep);
+  const bool last = keep || splits == 1 || fused;      // no slab reduce follows
   if (!transA && transB) CG_GEMM_LAUNCH(last, (gemm_f32_dma_kernel<BM, BN, false, true, KW, S>), grid, block, st, a);
   else if (!transA && !transB) CG_GEMM_LAUNCH(last, (gemm_f32_dma_kernel<BM, BN, false, false, KW, S>), grid, block, st, a);
   else if (transA && !transB) CG_GEMM_LAUNCH(last, (gemm_f32_dma_kernel<BM, BN, true, false, KW, S>), grid, block, st, a);
   else CG_GEMM_LAUNCH(last, (gemm_f32_dma_kernel<BM, BN, true, true, KW, S>), grid, block, st, a);
   if (keep) *keep = splits;
-  else if (splits > 1) launch_splitk_reduce(g, splits, st);
+  else if (splits > 1 && !fused) launch_splitk_reduce(g, splits, st);
   return cg_launch_status();
 }
 
@@ -1228,7 +1333,15 @@ int gemm_dispatch(float* C, int ldc, const void* A, int lda, const void* B, int 
   if (lda < a_cols || ldb < b_cols || ldc < N) return CG_ERR_BAD_ARG;
   if (E && lde < N) return CG_ERR_BAD_ARG;
   if (aux && ldaux < N) return CG_ERR_BAD_ARG;
-  if (dtype < 0 || dtype > (CG_BF16 | CG_A_IS_BF16 | CG_B_IS_BF16)) return CG_ERR_UNSUPPORTED;
+  if (dtype < 0 || dtype > (CG_BF16 | CG_A_IS_BF16 | CG_B_IS_BF16 | CG_WS_TILE_COUNTERS)) return CG_ERR_UNSUPPORTED;
+  unsigned* counters = nullptr;
+  if (dtype & CG_WS_TILE_COUNTERS) {      // the workspace ends with the tile arrival counters (see cgrna.h)
+    if (!workspace || workspace_bytes < 2 * WS_COUNTER_BYTES || workspace_bytes % 16 || (uintptr_t)workspace % 16)
+      return CG_ERR_BAD_ARG;
+    workspace_bytes -= WS_COUNTER_BYTES;
+    counters = (unsigned*)((char*)workspace + workspace_bytes);
+    dtype &= ~CG_WS_TILE_COUNTERS;
+  }
   const bool half = (dtype & CG_BF16) != 0, ah = (dtype & CG_A_IS_BF16) != 0, bh = (dtype & CG_B_IS_BF16) != 0;
   if ((ah || bh) && !half) return CG_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
@@ -1239,7 +1352,8 @@ int gemm_dispatch(float* C, int ldc, const void* A, int lda, const void* B, int 
   if (bh && (((uintptr_t)B % 8) || ldb % 4 || b_cols % 2)) return CG_ERR_UNSUPPORTED;
   if (a_bytes >= OOB_OFF || b_bytes >= OOB_OFF) return CG_ERR_UNSUPPORTED;   // 32-bit buffer offsets
   GemmArgs g{(const float*)A, (const float*)B, C, bias, E, aux, M, N, K, lda, ldb, ldc, lde, ldaux,
-             epi, accumulate, slope, 0, 1 << 30, (float*)workspace, (unsigned)a_bytes, (unsigned)b_bytes, (u16*)c_bf16};
+             epi, accumulate, slope, 0, 1 << 30, (float*)workspace, (unsigned)a_bytes, (unsigned)b_bytes, (u16*)c_bf16,
+             counters, 0};
   const bool tiny = K <= 16 || N <= 2 || (M <= 2 && transA && !transB) || (N <= 16 && !transA);
   if (tiny && (ah || bh)) return CG_ERR_UNSUPPORTED;      // the plain-FMA kernels read float32
   if (tiny && launch_small(g, transA, transB, st)) {

@@ -51,6 +51,10 @@ class HipOps:
     """The product backend: every method is one or two HIP kernel launches."""
 
     name = "hip"
+    WS_COUNTER_FLOATS = 16384 // 4
+    # cg_gemm `dtype` flag: the workspace ends with tile arrival counters, split-K products combine their slabs in the
+    # same launch (CGRNA_GEMM_SEPARATE_REDUCE in the environment keeps the second launch)
+    WS_TILE_COUNTERS = 8
 
     def __init__(self, device=None, precision="fp32"):
         """precision: 'fp32' - every product on the exact float32 MFMA;
@@ -80,11 +84,14 @@ class HipOps:
         key = torch.cuda.current_stream(self.device).cuda_stream
         ws = self._scratch.get(key)
         if ws is None:
-            ws = [torch.empty(32 << 20, dtype=torch.float32, device=self.device),     # 128 MiB split-K slabs
+            ws = [torch.empty((32 << 20) + self.WS_COUNTER_FLOATS, dtype=torch.float32, device=self.device),     # 128 MiB split-K slabs + counters
                   torch.empty(1 << 20, dtype=torch.float64, device=self.device)]      # 8 MiB BatchNorm chunk sums
             if os.environ.get("CGRNA_POISON_SCRATCH"):      # debugging aid: a kernel that reads scratch it did not write shows as NaN
                 ws[0].fill_(float("nan"))
                 ws[1].fill_(float("nan"))
+            # the slab scratch ends with the tile arrival counters of the split-K products (CG_WS_TILE_COUNTERS): zero
+            # once, every product leaves them zero
+            ws[0][-self.WS_COUNTER_FLOATS:].zero_()
             self._scratch[key] = ws
         return ws
 
@@ -310,19 +317,20 @@ class HipOps:
             assert epi == EPI_NONE and E is None and aux is None and not accumulate
             n_slabs = C.c_int(1)
             st = self.lib.cg_gemm_slabs(_ptr(Cm), _ld(Cm), pA, _ld(A), pB, _ld(B), M, N, K, int(transA), int(transB),
-                                        dtype, _ptr(bias), _ptr(self._ws()[0]), self._ws()[0].numel() * 4,
+                                        dtype, _ptr(bias), _ptr(self._ws()[0]),
+                                        (self._ws()[0].numel() - self.WS_COUNTER_FLOATS) * 4,
                                         C.addressof(n_slabs), self._stream())
         else:
             c16, _ = self._twin(Cm)
             st = self.lib.cg_gemm_ex(_ptr(Cm), _ld(Cm), pA, _ld(A), pB, _ld(B), M, N, K, int(transA), int(transB),
-                                     dtype, _ptr(bias), epi, _ptr(E), _ld(E), _ptr(aux), _ld(aux), float(slope),
+                                     dtype | self.WS_TILE_COUNTERS, _ptr(bias), epi, _ptr(E), _ld(E), _ptr(aux), _ld(aux), float(slope),
                                      int(accumulate), c16, _ptr(self._ws()[0]), self._ws()[0].numel() * 4,
                                      self._stream())
         if self._gemm_events is not None:       # the library has attached an event pair to this call's kernels
             elem = lambda flag: 2.0 if dtype & flag else 4.0  # noqa: E731
             self._gemm_events.append((2.0 * M * N * K,
                                       elem(4) * M * K + elem(2) * K * N + 4.0 * M * N * (2 if accumulate else 1),
-                                      (M, N, K, int(transA), int(transB), int(accumulate), dtype), self._gemm_skip))
+                                      (M, N, K, int(transA), int(transB), int(accumulate), dtype & 7), self._gemm_skip))
         _lib.check(st, "cg_gemm")
         return n_slabs.value if n_slabs is not None else None
 
@@ -357,7 +365,7 @@ class HipOps:
         M, N = X.shape
         assert Y.shape == X.shape and gamma.numel() == N and mean.numel() == N and invstd.numel() == N
         ws = self._ws()[0]
-        assert n_slabs >= 1 and n_slabs * M * N <= ws.numel()
+        assert n_slabs >= 1 and n_slabs * M * N <= ws.numel() - self.WS_COUNTER_FLOATS
         st = self.lib.cg_bn_fwd_slabs(_ptr(Y), _ld(Y), _ptr(X), _ld(X), _ptr(ws), n_slabs, _ptr(x_bias), M, N,
                                       _ptr(gamma), _ptr(beta), eps, _ptr(mean), _ptr(invstd), _ptr(rmean), _ptr(rvar),
                                       momentum, float(slope), _ptr(mask), _ld(mask), _ptr(pm), _ld(pm), *self._twin(Y),
@@ -425,7 +433,7 @@ class HipOps:
         M, N = X.shape
         assert dX.shape == X.shape
         ws = self._ws()[0]
-        assert n_slabs >= 1 and n_slabs * M * N <= ws.numel()
+        assert n_slabs >= 1 and n_slabs * M * N <= ws.numel() - self.WS_COUNTER_FLOATS
         st = self.lib.cg_bn_bwd_slabs(_ptr(dX), _ld(dX), _ptr(ws), n_slabs, _ptr(X), _ld(X), _ptr(Y), _ld(Y), _ptr(PM),
                                       _ld(PM), _ptr(mean), _ptr(invstd), _ptr(gamma), _ptr(dgamma), _ptr(dbeta),
                                       int(accumulate), float(slope), M, N, *self._twin(dX), self._stream())

@@ -43,6 +43,13 @@ extern "C" {
 #define CG_BF16 1
 #define CG_B_IS_BF16 2   /* B is stored as bf16 (ldb in bf16 elements) */
 #define CG_A_IS_BF16 4   /* A is stored as bf16 (lda in bf16 elements) */
+/* flag, with either arithmetic: the last 16384 bytes of `workspace` (16-byte aligned, workspace_bytes a multiple of
+ * 16 and at least 32768) are arrival counters of the output tiles: all zero before the first call that names them,
+ * and all zero again when any such call has finished.  A product that splits K then combines its partial sums in
+ * the same launch - the last workgroup to finish a tile adds that tile's slabs, in split order: the same bits as
+ * without the flag - instead of by a second launch.  Calls that may overlap on the device must use different
+ * workspaces, as for the slabs themselves. */
+#define CG_WS_TILE_COUNTERS 8
 
 int cg_version(void);
 

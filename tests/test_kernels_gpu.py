@@ -888,3 +888,93 @@ def test_label_colsum(ops, M, N, T):
     exp2 = torch.zeros(T, N)
     cpu.label_colsum(exp2, x, lab)
     close(plain, exp2, 1e-5)
+
+
+@pytest.mark.parametrize("M,N,K,ta,tb,epi,acc,dtype", [
+    (512, 1024, 2048, 0, 1, EPI_LEAKY, 0, 0), (512, 2048, 5000, 0, 1, EPI_NONE, 0, 0), (512, 512, 1024, 0, 1, EPI_NONE, 0, 0),
+    (256, 512, 1024, 1, 0, EPI_NONE, 1, 0), (512, 268, 2048, 0, 0, EPI_MUL, 0, 0), (1024, 1024, 5012, 0, 1, EPI_NONE, 0, 0),
+    (130, 70, 3000, 0, 1, EPI_NONE, 0, 0), (131, 67, 2999, 1, 1, EPI_LEAKY, 0, 0), (512, 1024, 2048, 0, 1, EPI_LEAKY, 0, 1),
+    (512, 512, 5000, 0, 0, EPI_NONE, 1, 1), (100, 36, 4000, 0, 1, EPI_NONE, 0, 1)])
+def test_gemm_split_k_combined_in_the_kernel(M, N, K, ta, tb, epi, acc, dtype):
+    """CG_WS_TILE_COUNTERS: a product that splits K and combines its slabs in the same launch (the last workgroup of
+    each output tile adds them in split order) returns the bits of the two-launch form, whatever the arrival order
+    (repeated calls), with every epilogue, with accumulation, on both MFMA paths, for sizes that are no multiple of
+    a tile or of four; the counters are zero again afterwards."""
+    import ctypes as C
+    from cycle_gan_rna_amd import _lib
+    lib = _lib.load_ctypes()
+    A = dev(rnd(*((K, M) if ta else (M, K)), seed=1))
+    B = dev(rnd(*((N, K) if tb else (K, N)), seed=2))
+    bias = None if acc else dev(rnd(N, seed=3))
+    E = dev((torch.rand(M, N, generator=torch.Generator().manual_seed(4)) < 0.7).float() / 0.7) if epi != EPI_NONE else None
+    base = dev(rnd(M, N, seed=5))
+    ws_floats = 8 * M * N + 4096
+    ws = torch.full((ws_floats,), float("nan")).cuda()
+    ws[-4096:].zero_()
+    st = torch.cuda.current_stream().cuda_stream
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+
+    def run(flag):
+        out = base.clone()
+        aux = torch.zeros(M, N).cuda() if epi == EPI_LEAKY else None
+        rc = lib.cg_gemm(p(out), N, p(A), A.shape[1], p(B), B.shape[1], M, N, K, ta, tb, dtype | flag, p(bias), epi, p(E), N,
+                         p(aux), N, 0.2, acc, p(ws), (ws_floats if flag else ws_floats - 4096) * 4, C.c_void_p(st))
+        assert rc == 0, rc
+        return out, aux
+    ref, ref_aux = run(0)
+    for _ in range(10):
+        got, got_aux = run(8)
+        assert torch.equal(got, ref)
+        assert ref_aux is None or torch.equal(got_aux, ref_aux)
+    torch.cuda.synchronize()
+    assert int(ws[-4096:].view(torch.int32).abs().max()) == 0
+    exp = torch.empty(M, N)
+    cpu.gemm(exp, A.cpu().double() if dtype == 0 else A.cpu().bfloat16().double(),
+             B.cpu().double() if dtype == 0 else B.cpu().bfloat16().double(), ta, tb,
+             bias=None if bias is None else bias.cpu().double())
+    if epi == EPI_NONE:
+        close(ref, exp + (base.cpu() if acc else 0), 2e-5, "split-K product")
+
+
+def test_gemm_split_k_combined_in_the_kernel_under_load(ops):
+    """The in-kernel combine hands slabs from workgroup to workgroup inside one launch (write-through stores, an
+    arrival counter, loads that bypass the CU's cache): checked word for word against the two-launch results while a
+    second stream keeps part of the chip busy with other products, with one workspace reused by products of
+    different shapes back to back (the reader's caches have seen those addresses before), 60 rounds."""
+    shapes = [(512, 1024, 2048, 0, 1), (512, 268, 2048, 0, 0), (1024, 1024, 5012, 0, 1), (512, 512, 1024, 1, 0),
+              (512, 2048, 5000, 0, 1), (256, 512, 1024, 1, 0)]
+    import os
+    cases = []
+    for i, (M, N, K, ta, tb) in enumerate(shapes):
+        A = dev(rnd(*((K, M) if ta else (M, K)), seed=10 + i))
+        B = dev(rnd(*((N, K) if tb else (K, N)), seed=20 + i))
+        cases.append((A, B, ta, tb, torch.empty(M, N).cuda(), torch.empty(M, N).cuda()))
+    side = ops.stream("side0")
+    X, Y, Z = dev(rnd(2048, 2048, seed=1)), dev(rnd(2048, 2048, seed=2)), torch.empty(2048, 2048).cuda()
+    # reference: the same products without the flag (two launches), through the C ABI
+    import ctypes as C
+    from cycle_gan_rna_amd import _lib
+    lib = _lib.load_ctypes()
+    ws = ops._ws()[0]
+    st = torch.cuda.current_stream().cuda_stream
+    for A, B, ta, tb, ref, _ in cases:
+        M, N = ref.shape
+        K = A.shape[0] if ta else A.shape[1]
+        rc = lib.cg_gemm(C.c_void_p(ref.data_ptr()), N, C.c_void_p(A.data_ptr()), A.shape[1], C.c_void_p(B.data_ptr()),
+                         B.shape[1], M, N, K, ta, tb, 0, None, 0, None, 0, None, 0, 0.0, 0, C.c_void_p(ws.data_ptr()),
+                         (ws.numel() - ops.WS_COUNTER_FLOATS) * 4, C.c_void_p(st))
+        assert rc == 0
+    torch.cuda.synchronize()
+    bad = 0
+    for rnd_i in range(60):
+        with torch.cuda.stream(side):
+            for _ in range(1 + rnd_i % 3):
+                ops.gemm(Z, X, Y)
+        for A, B, ta, tb, ref, out in cases:
+            out.fill_(float("nan"))
+            ops.gemm(out, A, B, ta, tb)
+            bad += int((out != ref).sum())
+    torch.cuda.synchronize()
+    assert bad == 0, f"{bad} words differ from the two-launch product"
+    assert int(ws[-ops.WS_COUNTER_FLOATS:].view(torch.int32).abs().max()) == 0
+    assert not os.environ.get("CGRNA_GEMM_SEPARATE_REDUCE"), "the test compared the two-launch form with itself"
