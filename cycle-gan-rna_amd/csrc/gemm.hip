@@ -1055,26 +1055,30 @@ __global__ void __launch_bounds__(256) gemm_small_k_kernel(GemmArgs g, Strides s
   }
 }
 
-// N <= 2, op(A) with k contiguous: one wave per output row, lanes stride over k, butterfly sum over the lanes.
+// op(A) with k contiguous and few outputs (N <= 2: the critic's one-column head; or a handful of rows and up to 16
+// columns: the embedding tables' gradient from the per-label sums, 12 x 12 with K = 1024): one wave per output row
+// and pair of columns, lanes stride over k, butterfly sum over the lanes.
 __global__ void __launch_bounds__(256) gemm_small_n_kernel(GemmArgs g, Strides st) {
-  const int lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int pairs = (g.N + 1) >> 1, w = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, m = w / pairs, n0 = 2 * (w - m * pairs);
   if (m >= g.M) return;
   float acc[2] = {0.f, 0.f};
   const float* a = g.A + (size_t)m * st.am;
+  const bool two = n0 + 1 < g.N;
+#pragma unroll 4
   for (int k = lane; k < g.K; k += 64) {
     const float av = a[k * st.ak];
-    const float* b = g.B + (size_t)k * st.bk;
-#pragma unroll
-    for (int n = 0; n < 2; ++n)
-      if (n < g.N) acc[n] += av * b[n * st.bn];
+    const float* b = g.B + (size_t)k * st.bk + (size_t)n0 * st.bn;
+    acc[0] += av * b[0];
+    if (two) acc[1] += av * b[st.bn];
   }
 #pragma unroll
   for (int n = 0; n < 2; ++n) {
-    if (n >= g.N) break;
+    if (n0 + n >= g.N) break;
     float v = acc[n];
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    if (lane == 0) epilogue_store(g, m, n, v + (g.bias ? g.bias[n] : 0.f));
+    if (lane == 0) epilogue_store(g, m, n0 + n, v + (g.bias ? g.bias[n0 + n] : 0.f));
   }
 }
 
@@ -1199,8 +1203,9 @@ bool launch_small(const GemmArgs& g, int transA, int transB, hipStream_t st) {
   }
   // a few columns: every wave reads B once per row it owns, which stays cheap while B is a few vectors (measured:
   // the one-column head 7 us against 13 us for the tiled kernel; twelve columns 40 us against 13 us)
-  if (g.N <= 2 && !transA) {
-    CG_GEMM_LAUNCH(true, gemm_small_n_kernel, dim3((g.M + 3) / 4), dim3(256), st, g, s);
+  if (!transA && (g.N <= 2 || (g.N <= 16 && g.M <= 32))) {
+    const int waves = g.M * ((g.N + 1) / 2);
+    CG_GEMM_LAUNCH(true, gemm_small_n_kernel, dim3((waves + 3) / 4), dim3(256), st, g, s);
     return true;
   }
   if (g.N <= 16 && !transA) {

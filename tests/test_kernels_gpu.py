@@ -657,7 +657,8 @@ def test_token_residual_block_shapes_through_general_kernels(ops, D):
     (512, 256, 1, 0, 0, EPI_MUL, 0), (300, 7, 100, 0, 0, EPI_LEAKY, 0), (130, 1024, 12, 0, 1, EPI_NONE, 1),
     (9, 200, 333, 1, 0, EPI_LEAKY, 0), (16, 130, 64, 0, 0, EPI_NONE, 1), (257, 16, 70, 0, 1, EPI_MUL, 0),
     (5, 3, 2, 1, 1, EPI_NONE, 0), (1024, 12, 1024, 0, 0, EPI_NONE, 0), (100, 3, 1300, 0, 1, EPI_NONE, 1),
-    (7, 16, 600, 0, 0, EPI_MUL, 0), (515, 5, 64, 0, 0, EPI_NONE, 0)])
+    (7, 16, 600, 0, 0, EPI_MUL, 0), (515, 5, 64, 0, 0, EPI_NONE, 0), (12, 12, 1024, 0, 0, EPI_NONE, 1),
+    (32, 15, 700, 0, 1, EPI_LEAKY, 0)])
 def test_gemm_small_dimension_kernels(ops, M, N, K, ta, tb, epi, acc):
     """Products with M, N or K <= 16 take plain-FMA kernels (the critic's head, the embedding slice of its first
     layer, rank-one products): same results and epilogues as the tiled kernel, operands that are column slices."""
