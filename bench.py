@@ -390,8 +390,8 @@ def main():
         pmc = _profile_json("r03_pmc_%s.json" % tag) or _profile_json("r02_pmc_%s.json" % tag)
         if pmc and (G, B) == (G_GENES, BATCH):
             fam = [v for k, v in pmc["kernels"].items() if k.startswith("gemm")]
-            if fam:
-                traffic = sum(f["hbm_bytes_per_launch"] * f["launches"] for f in fam) / sum(f["launches"] for f in fam)
+            if fam:     # bytes of every kernel of the GEMM family in an iteration, per cg_gemm call (as `achieved` is)
+                traffic = sum(f["hbm_bytes_per_launch"] * f["launches_per_iteration"] for f in fam) / (n_launch / NB_CRITIC)
             mfma = pmc.get("mfma")
         alg_flop = algorithmic_gflop_per_cell_iteration(G) * 1e9 * B * NB_CRITIC
         # achieved: the FLOPs actually issued through cg_gemm (all of them algorithmically necessary; 2-3 % of the
@@ -403,7 +403,7 @@ def main():
                  "the small products" if a.dtype == "bf16"
                  else "gemm_f32_dma_kernel / gemm_f32_kernel (v_mfma_f32_32x32x2_f32)")
         roof = dict(bound="mfma", achieved=achieved, peak=peak, unit="TFLOP/s",
-                    frac=achieved / peak, traffic=traffic, traffic_unit="HBM bytes per launch (rocprofv3 PMC)",
+                    frac=achieved / peak, traffic=traffic, traffic_unit="HBM bytes per cg_gemm call (rocprofv3 PMC: all kernels of the GEMM family in an iteration / calls in an iteration)",
                     operand_bytes_per_launch=gemm_bytes / n_launch,
                     kernel=kname, launches_per_iteration=n_launch / NB_CRITIC,
                     avg_launch_us=gemm_ms * 1e3 / n_launch, gemm_ms_per_iteration=gemm_ms / NB_CRITIC,

@@ -383,8 +383,10 @@ __device__ __forceinline__ bf16x8 fragment(const u16* s, int row0, int kbase, in
 
 // One output element (VEC4: four consecutive columns, 16-byte accesses) from the split-K partial sums: the bias, then
 // the slabs in split order, then the epilogue of cg_gemm.
+// own (with own_split >= 0): this workgroup's own slab, still in LDS, taken from there instead of from memory.
 template <bool VEC4, bool SC1 = false>
-__device__ __forceinline__ void combine_slabs(const GemmArgs& g, int splits, int m, int n) {
+__device__ __forceinline__ void combine_slabs(const GemmArgs& g, int splits, int m, int n, int own_split = -1,
+                                              const float* own = nullptr) {
   constexpr int W = VEC4 ? 4 : 1;
   const size_t e0 = (size_t)m * g.N + n;
   float h[W];
@@ -394,7 +396,7 @@ __device__ __forceinline__ void combine_slabs(const GemmArgs& g, int splits, int
     const float* p = g.ws + (size_t)k * g.M * g.N + e0;
     if (VEC4) {
       // SC1: slabs stored write-through by other workgroups of this launch are read past this CU's L1
-      const f32x4 v = SC1 ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+      const f32x4 v = k == own_split ? *reinterpret_cast<const f32x4*>(own) : SC1 ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
                                 make_rsrc(g.ws, 0xfffffff0u), (unsigned)(((size_t)k * g.M * g.N + e0) * 4), 0, 16))
                           : *reinterpret_cast<const f32x4*>(p);
 #pragma unroll
@@ -460,8 +462,10 @@ __device__ __forceinline__ void combine_slabs(const GemmArgs& g, int splits, int
 // happens to arrive last - and puts the counter back to 0 for the next product that uses it.  No workgroup ever
 // waits for another.  Every thread of the workgroup must call this (two barriers); `flag`: one int of LDS that
 // nothing else uses any more.
+// own_tile (may be nullptr): the workgroup's partial sums as [BM][BN + 4] floats in LDS, slab own_split.
 template <int BM, int BN, int NT>
-__device__ __forceinline__ void split_tail(const GemmArgs& g, int tile, int bm, int bn, int* flag) {
+__device__ __forceinline__ void split_tail(const GemmArgs& g, int tile, int bm, int bn, int* flag, int own_split = -1,
+                                           const float* own_tile = nullptr) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's write-through slab stores have been acknowledged
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -476,7 +480,8 @@ __device__ __forceinline__ void split_tail(const GemmArgs& g, int tile, int bm, 
   if (g.vec4) {
     for (int i = threadIdx.x; i < BM * BN / 4; i += NT) {
       const int m = bm + i / (BN / 4), n = bn + 4 * (i % (BN / 4));
-      if (m < g.M && n < g.N) combine_slabs<true, true>(g, splits, m, n);
+      if (m < g.M && n < g.N)
+        combine_slabs<true, true>(g, splits, m, n, own_tile ? own_split : -1, own_tile + (i / (BN / 4)) * (BN + 4) + 4 * (i % (BN / 4)));
     }
   } else {
     for (int i = threadIdx.x; i < BM * BN; i += NT) {
@@ -668,7 +673,7 @@ __device__ __forceinline__ void finish_f32(const GemmArgs& g, f32x16 (&acc)[TM][
         __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(smem + r * LDT + c), rs,
                                                (unsigned)((slab + (size_t)row * g.N + col) * 4), 0, 16);   // 16: sc1
     }
-    split_tail<BM, BN, NT>(g, tile, bm, bn, reinterpret_cast<int*>(smem));
+    split_tail<BM, BN, NT>(g, tile, bm, bn, reinterpret_cast<int*>(smem + BN), split, smem);   // the flag in the padding of the tile's first row
     return;
   }
   if (gridDim.y > 1) {   // split-K: raw partial sums, combined by split_tail, splitk_reduce_kernel or the consumer
@@ -732,6 +737,7 @@ __global__ void __launch_bounds__(256 * KW) gemm_f32_kernel(GemmArgs g) {
   constexpr int CG = BK / 8 / KW;   // groups of eight k per slab handled by one wave group
   static_assert(CG * KW * 8 == BK, "K slab does not divide over the wave groups");
   static_assert(KW == 1 || TM * TN * 16 * 256 * (KW - 1) <= 2 * (A_ELEMS + B_ELEMS), "accumulator exchange does not fit in LDS");
+  static_assert(BM * (BN + 4) <= 2 * (A_ELEMS + B_ELEMS), "the output tile (finish_f32, split-K tail) does not fit in LDS");
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -892,6 +898,7 @@ __global__ void __launch_bounds__(256 * KW) gemm_f32_dma_kernel(GemmArgs g) {
   constexpr int A_ELEMS = BM * BK, B_ELEMS = BN * BK, STAGE = A_ELEMS + B_ELEMS;
   static_assert(S >= 3, "needs at least three LDS stages");
   static_assert(KW == 1 || TM * TN * 16 * 256 * (KW - 1) <= S * STAGE, "accumulator exchange does not fit in LDS");
+  static_assert(BM * (BN + 4) <= S * STAGE, "the output tile (finish_f32, split-K tail) does not fit in LDS");
   __shared__ __align__(16) float smem[S * STAGE];      // the kernel's only LDS object
 
   int tile, split;
