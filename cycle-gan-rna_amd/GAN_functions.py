@@ -610,8 +610,17 @@ def train_enhanced_cycle_gan(g_m2h, g_h2m, d_m, d_h, mouse_adata, human_adata,
             key_map = key_map + (('identity_loss', 'identity_loss'),)
             metrics['identity_loss'] = []
         last = {}
+        # the metrics of a generator step are read back one generator step late (and at the end of the epoch), so the
+        # host does not stop issuing work while they travel; 'deferred_metrics': False reads them at once
+        how = "deferred" if config.get('deferred_metrics', True) else True
         for epoch in epochs:
             acc = {k: [] for k, _ in key_map}
+            pending = []
+
+            def record(out):
+                for k, src in key_map:
+                    acc[k].append(out[src])
+                return out
             mouse_iter, human_iter = iter(mouse_loader), iter(human_loader)
 
             def epoch_batches(mouse_iter=mouse_iter, human_iter=human_iter):
@@ -640,12 +649,15 @@ def train_enhanced_cycle_gan(g_m2h, g_h2m, d_m, d_h, mouse_adata, human_adata,
                 i, batch = cur
                 if hasattr(noise, "begin_step"):
                     noise.begin_step()
-                out = eng.iteration(i, *batch, noise, nxt=None if nxt is None else nxt[1])
+                out = eng.iteration(i, *batch, noise, nxt=None if nxt is None else nxt[1], metrics=how)
                 if out:                                                                            # :411-419
-                    last = out
-                    for k, src in key_map:
-                        acc[k].append(out[src])
+                    pending.append(out)
+                    while len(pending) > (1 if how == "deferred" else 0):
+                        out = pending.pop(0)
+                        last = record(out if isinstance(out, dict) else out.get())
                 cur = nxt if eng.lookahead else next(batches, None)
+            for out in pending:
+                last = record(out if isinstance(out, dict) else out.get())
             if config['use_lr_decay']:                                                             # :421
                 current_lr, new_lr = _lr_decay_step(config, epoch)
                 if new_lr is not None:

@@ -947,6 +947,42 @@ class CriticStack:
         ops.colsum(G["model.9.weight"], vu3, 1.0, True)
 
 
+class PendingMetrics:
+    """The metrics of a generator step (GAN_functions.py:411-419) on their way to the host: iteration(...,
+    metrics="deferred") queues the copies of the loss records into pinned memory behind the step and returns this
+    instead of waiting for them, so the host can go on issuing the next iterations; get() waits for the copies (not
+    for anything issued later) and returns the dict that metrics=True would have returned."""
+
+    _free = {}      # device -> pinned staging buffers not in use
+
+    def __init__(self, eng, critic):
+        self.eng, self.critic = eng, critic
+        dev = eng.ops.device
+        pool = PendingMetrics._free.setdefault(dev, [])
+        self.buf = pool.pop() if pool else (torch.empty(eng.d_tot.numel(), dtype=eng.d_tot.dtype).pin_memory(),
+                                            torch.empty(eng.gloss.numel(), dtype=eng.gloss.dtype).pin_memory(),
+                                            torch.empty(eng.var_out.numel(), dtype=eng.var_out.dtype).pin_memory())
+        for dst, src in zip(self.buf, (eng.d_tot, eng.gloss, eng.var_out)):
+            assert dst.numel() == src.numel() and dst.dtype == src.dtype
+            dst.copy_(src.view(-1), non_blocking=True)
+        self.event = torch.cuda.Event()
+        self.event.record(torch.cuda.current_stream(dev))
+        self.value = None
+
+    def get(self):
+        if self.value is None:
+            self.event.synchronize()
+            d, g, v = self.buf
+            out = {}
+            if self.critic:
+                out.update(self.eng.d_losses(d))
+            out.update(self.eng.g_losses(g, v))
+            self.value = out
+            PendingMetrics._free[self.eng.ops.device].append(self.buf)
+            self.buf = self.eng = None
+        return self.value
+
+
 # graphs and events of engines that were dropped while a capture was running in the same thread: EngineBase.close()
 # releases them once no capture is running
 _DEFERRED_RELEASES = []
@@ -1446,8 +1482,9 @@ class StepEngine(EngineBase):
         if self.sync.enabled:       # one rank: done in the critics' backward branches (_d_critics)
             self._adam(self.arena_d)
 
-    def d_losses(self):
-        t = self.d_tot.cpu()
+    def d_losses(self, t=None):
+        """t: a host copy of the critic step's six loss sums (default: read now, which waits for the device)."""
+        t = self.d_tot.cpu() if t is None else t
         f32 = lambda v: float(torch.tensor(v, dtype=torch.float32))  # noqa: E731
         return dict(d_m_loss=f32(float(t[0]) + float(t[1]) + float(t[2])),
                     d_h_loss=f32(float(t[3]) + float(t[4]) + float(t[5])),
@@ -1705,9 +1742,10 @@ class StepEngine(EngineBase):
             self.ext_weights = self.ops.zeros(5)
         self.ext_weights.copy_(self.ops.to_device(w))
 
-    def g_losses(self):
-        t = self.gloss.cpu()
-        v = self.var_out.cpu()
+    def g_losses(self, t=None, v=None):
+        """t, v: host copies of the generator step's loss record and variance metrics (default: read now)."""
+        t = self.gloss.cpu() if t is None else t
+        v = self.var_out.cpu() if v is None else v
         f32 = lambda x: float(torch.tensor(float(x), dtype=torch.float32))  # noqa: E731
         return dict(g_adv=float(t[0]), cycle_loss=float(t[1]), celltype_loss=float(t[2]), fm_loss=float(t[3]),
                     kl_loss=float(t[4]), g_loss=f32(t[5]), identity_loss=float(t[11]),
@@ -1737,6 +1775,8 @@ class StepEngine(EngineBase):
                     self._g_encoder_of = None
         out = {}
         if metrics and i % self.cfg["nb_critic"] == 0:
+            if metrics == "deferred" and self.ops.device.type == "cuda":
+                return PendingMetrics(self, critic)
             if critic:
                 out.update(self.d_losses())
             out.update(self.g_losses())

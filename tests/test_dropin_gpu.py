@@ -210,8 +210,9 @@ def test_train_function_default_mode_replays_graphs(identity, iters_per_epoch):
     res = {}
     cwd = os.getcwd()
     for mode in ("fast", "plain"):
+        # the plain run also reads every generator step's metrics at once instead of one generator step late
         cfg = dict(fx["cfg"], device="cuda", progress=False, epochs=4, hip_graphs=mode == "fast",
-                   concurrent_streams=mode == "fast")
+                   concurrent_streams=mode == "fast", deferred_metrics=mode == "fast")
         if identity:
             cfg["lambda_identity"] = 0.5
         mods = build_modules(gm, gh, cfg, fx["init_seed"])
