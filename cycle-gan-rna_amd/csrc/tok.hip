@@ -105,20 +105,21 @@ __device__ __forceinline__ void block_stats(double* part, const Row& a, const Ro
 }
 
 // Re-add the per-workgroup partials; tot: 32 doubles in LDS, valid after the call.  Each quarter of the workgroup
-// adds a contiguous quarter of the partials in workgroup order (eight loads in flight at a time: the loads, not the
-// additions, are what takes time), then the four sums are added in quarter order: a fixed order, the same bits on
-// every run.  red4: 4*32 doubles of LDS that nothing else is using at this point.
+// adds a contiguous quarter of the partials in workgroup order (sixteen loads in flight at a time - a quarter's whole
+// share at batch 512, one round trip: the loads, not the additions, are what takes time), then the four sums are
+// added in quarter order: a fixed order, the same bits on every run.  red4: 4*32 doubles of LDS that nothing else is
+// using at this point.
 __device__ __forceinline__ void total_stats(double* tot, const double* part, int nblk, double* red4) {
   const int s = threadIdx.x & 31, q = threadIdx.x >> 5;
   const int per = (nblk + 3) >> 2;
   const int b0 = q * per, b1 = min(nblk, b0 + per);
   double a = 0.0;
-  for (int b = b0; b < b1; b += 8) {
-    double v[8];
+  for (int b = b0; b < b1; b += 16) {
+    double v[16];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) v[k] = part[(size_t)min(b + k, nblk - 1) * 32 + s];
+    for (int k = 0; k < 16; ++k) v[k] = part[(size_t)min(b + k, nblk - 1) * 32 + s];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) a += b + k < b1 ? v[k] : 0.0;
+    for (int k = 0; k < 16; ++k) a += b + k < b1 ? v[k] : 0.0;
   }
   red4[q * 32 + s] = a;
   __syncthreads();
