@@ -1,4 +1,4 @@
-# Measurements of the current build, on the GPU box (run from the repository root): the default bench line, rocprofv3
+# Measurements of the current build, on the GPU box (run from the repository root): rocprofv3
 # kernel statistics of the step on one stream (float32 and bf16 mode), and three counter passes per mode (HBM read
 # bytes, HBM written bytes, matrix-core counters; separate runs, counters only with --kernel-trace).  Writes under
 # gpurun_out/r03/; tools/profile_summary.py turns the passes into profiles/r03_pmc_<mode>.json.
@@ -6,8 +6,6 @@ set -e -o pipefail
 R=$PWD
 O=$R/gpurun_out/r03
 mkdir -p $O
-timeout -k 10 600 python3 bench.py > $O/bench.json 2> $O/bench.err
-echo "bench done"
 cd /tmp && export TMPDIR=/tmp
 for mode in f32 bf16; do
   rm -rf $O/ks_$mode $O/pf_$mode $O/pw_$mode $O/pm_$mode
@@ -22,4 +20,13 @@ for mode in f32 bf16; do
   # the raw traces are large; the summaries are what travels back
   rm -rf $O/ks_$mode $O/pf_$mode $O/pw_$mode $O/pm_$mode
 done
+# the bench line last, so that its counter figures (roofline.traffic, mfma_counters) are those of this build: bench.py
+# reads them from profiles/r03_pmc_<mode>.json
+for mode in f32 bf16; do
+  cp $O/pmc_$mode.json $R/profiles/r03_pmc_$mode.json
+  cp $O/${mode}_sequential_kernel_stats.csv $R/profiles/r03_${mode}_sequential_kernel_stats.csv
+done
+cd $R
+timeout -k 10 900 python3 bench.py > $O/bench.json 2> $O/bench.err
+echo "bench done"
 cut -c1-300 $O/bench.json
