@@ -90,6 +90,9 @@ SIGNATURES = {
     "cg_sum_parts": ([P, P, P, P, P, I, P], I),
     "cg_adam_amsgrad": ([P, P, P, P, P, Z, P, F, F, F, P, P], I),
     "cg_attn_ln_fwd": ([P, P, P, P, I, I, I, P], I),
+    "cg_attn_block_blocks": ([I], I),
+    "cg_attn_block_fwd": ([P, P, P, P, P, I, P, P, F, P, P, P, P, F, P, P, I, I, I, P, P, P, P, P], I),
+    "cg_tok_bn_lin_fwd_from": ([P, P, P, P, P, I, P, P, F, P, P, P, P, F, P, P, I, P], I),
     "cg_attn_bwd_blocks": ([I], I),
     "cg_attn_bwd_ws": ([I, I, I], C.c_longlong),
     "cg_attn_ln_bwd": ([P, P, P, P, P, P, P, I, I, I, I, P], I),

@@ -46,17 +46,21 @@ struct WaveLdsFwd {
   float os[S][E];
 };
 
-__device__ __forceinline__ void forward_core(Fwd& f, const float* __restrict__ X, const float* __restrict__ keep,
-                                             const float* W /* LDS params */, WaveLdsFwd& L, int cell, int i, int h) {
+// Token i of `cell` into f.x, and this lane's own four features (4h .. 4h+3) into xown - fetched by address: indexing
+// f.x with the lane's head would put the whole struct into scratch memory.
+__device__ __forceinline__ void load_token(Fwd& f, f32x4& xown, const float* __restrict__ X, int cell, int i, int h) {
   const f32x4* xr = reinterpret_cast<const f32x4*>(X + ((size_t)cell * S + i) * E);
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     const f32x4 t = xr[c];
     f.x[4 * c] = t[0]; f.x[4 * c + 1] = t[1]; f.x[4 * c + 2] = t[2]; f.x[4 * c + 3] = t[3];
   }
-  // this lane's own four features, fetched by address: indexing f.x with the lane's head would put the
-  // whole struct into scratch memory
-  const f32x4 xown = xr[h];
+  xown = xr[h];
+}
+
+// The forward of one cell from f.x / xown (load_token, or the fused block kernel's own prologue).
+__device__ __forceinline__ void forward_core(Fwd& f, const f32x4 xown, const float* __restrict__ keep,
+                                             const float* W /* LDS params */, WaveLdsFwd& L, int cell, int i, int h) {
 #pragma unroll
   for (int c = 0; c < HD; ++c) {
     float q = W[OFF_BIN + 4 * h + c], k = W[OFF_BIN + 16 + 4 * h + c], v = W[OFF_BIN + 32 + 4 * h + c];
@@ -150,7 +154,9 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(float* __restrict__ Y, co
     const bool valid = cell_raw < n_cells;
     const int cell = valid ? cell_raw : n_cells - 1;
     Fwd f;
-    forward_core(f, X, keep, W, lds[wave], cell, i, h);
+    f32x4 xown;
+    load_token(f, xown, X, cell, i, h);
+    forward_core(f, xown, keep, W, lds[wave], cell, i, h);
     if (valid) {
       f32x4 y;
 #pragma unroll
@@ -158,6 +164,153 @@ __global__ void __launch_bounds__(256) attn_fwd_kernel(float* __restrict__ Y, co
       *reinterpret_cast<f32x4*>(Y + ((size_t)cell * S + i) * E + 4 * h) = y;
     }
     __syncthreads();
+  }
+}
+
+// The attention of a residual-attention block together with the steps of the token ResidualBlocks on either side of
+// it (GAN_functions.py:54-68, :28-36, :142-145), which need no statistic of their own:
+//   before  x = xin + bn2(t2)                - the block's last step (tok_bn_res_fwd in tok.hip): the column totals of
+//           t2 are re-added from the per-workgroup partials exactly as there, x goes to Xres (the backward pass reads it)
+//   after   t1 = y W1^T + b1 of the NEXT block - its first step (tok_lin_fwd) - with the column sums of t1 and t1^2
+//           per workgroup of this launch (POST; stat_out[gridDim.x][32], float64, fixed order of additions)
+// Two launches per block instead of four.
+struct BlockFuse {
+  const float* T2; const float* Xin; const double* stat_in; int n_stat_in;
+  const float* gamma; const float* beta; float eps;
+  float* mean_out; float* invstd_out; float* rmean; float* rvar; float momentum;
+  float* Xres; int n_tok;
+  float* T1; double* stat_out; const float* W1; const float* b1;
+};
+
+template <bool POST>
+__global__ void __launch_bounds__(256) attn_block_fwd_kernel(float* __restrict__ Y, const float* __restrict__ keep,
+                                                             const float* __restrict__ params, int n_cells, int iters,
+                                                             BlockFuse bf) {
+  __shared__ __align__(16) float W[NPARAM];
+  __shared__ __align__(16) WaveLdsFwd lds[4];
+  __shared__ double red[4 * 32], tot[32], wsum[4][32];
+  __shared__ float cmean[E], cinv[E], cgam[E], cbet[E];
+  __shared__ float w1[E * E], b1s[E];
+  for (int t = threadIdx.x; t < NPARAM; t += 256) W[t] = params[t];
+  if (POST) {
+    w1[threadIdx.x] = bf.W1[threadIdx.x];
+    if (threadIdx.x < E) b1s[threadIdx.x] = bf.b1[threadIdx.x];
+    if (threadIdx.x < 128) wsum[threadIdx.x >> 5][threadIdx.x & 31] = 0.0;
+  }
+  // column totals of t2 from the partials: the additions of tok.hip's total_stats, in its order
+  if (threadIdx.x < 128) {
+    const int s = threadIdx.x & 31, q = threadIdx.x >> 5, nblk = bf.n_stat_in;
+    const int per = (nblk + 3) >> 2;
+    const int b0 = q * per, b1 = min(nblk, b0 + per);
+    double a = 0.0;
+    for (int b = b0; b < b1; b += 16) {
+      double v[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) v[k] = bf.stat_in[(size_t)min(b + k, nblk - 1) * 32 + s];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) a += b + k < b1 ? v[k] : 0.0;
+    }
+    red[q * 32 + s] = a;
+  }
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const int s = threadIdx.x;
+    tot[s] = ((red[s] + red[32 + s]) + red[64 + s]) + red[96 + s];
+  }
+  __syncthreads();
+  if (threadIdx.x < E) {      // as bn_fwd_cols in tok.hip
+    const int c = threadIdx.x, n_tok = bf.n_tok;
+    const double mean_d = tot[c] / n_tok;
+    double var_d = tot[16 + c] / n_tok - mean_d * mean_d;
+    if (var_d < 0.0) var_d = 0.0;
+    const float mean = (float)mean_d, invstd = (float)(1.0 / sqrt(var_d + (double)bf.eps));
+    cmean[c] = mean;
+    cinv[c] = invstd;
+    cgam[c] = bf.gamma[c];
+    cbet[c] = bf.beta[c];
+    if (blockIdx.x == 0) {
+      bf.mean_out[c] = mean;
+      bf.invstd_out[c] = invstd;
+      if (bf.rmean) bf.rmean[c] = (1.f - bf.momentum) * bf.rmean[c] + bf.momentum * mean;
+      if (bf.rvar) {
+        const float unb = (float)(var_d * ((double)n_tok / (double)(n_tok > 1 ? n_tok - 1 : 1)));
+        bf.rvar[c] = (1.f - bf.momentum) * bf.rvar[c] + bf.momentum * unb;
+      }
+    }
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 15, h = lane >> 4;
+  for (int it = 0; it < iters; ++it) {
+    const int cell_raw = (it * gridDim.x + blockIdx.x) * 4 + wave;
+    const bool valid = cell_raw < n_cells;
+    const int cell = valid ? cell_raw : n_cells - 1;
+    Fwd f;
+    f32x4 xown;
+    {
+      const size_t row = ((size_t)cell * S + i) * E;
+      const f32x4* tr = reinterpret_cast<const f32x4*>(bf.T2 + row);
+      const f32x4* xr = reinterpret_cast<const f32x4*>(bf.Xin + row);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const f32x4 t = tr[c], x = xr[c];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int e = 4 * c + u;
+          const float bn = (t[u] - cmean[e]) * cinv[e] * cgam[e] + cbet[e];
+          f.x[e] = 1.0f * x[u] + 1.0f * bn;
+        }
+      }
+      const f32x4 t = tr[h], x = xr[h];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int e = 4 * h + u;
+        const float bn = (t[u] - cmean[e]) * cinv[e] * cgam[e] + cbet[e];
+        xown[u] = 1.0f * x[u] + 1.0f * bn;
+      }
+      if (valid) *reinterpret_cast<f32x4*>(bf.Xres + row + 4 * h) = xown;
+    }
+    WaveLdsFwd& L = lds[wave];
+    forward_core(f, xown, keep, W, L, cell, i, h);
+    f32x4 y;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) y[c] = f.xhat[c] * W[OFF_LNW + 4 * h + c] + W[OFF_LNB + 4 * h + c];
+    if (valid) *reinterpret_cast<f32x4*>(Y + ((size_t)cell * S + i) * E + 4 * h) = y;
+    if (POST) {
+      __syncthreads();      // every lane has read the concatenated heads from L.os
+#pragma unroll
+      for (int c = 0; c < HD; ++c) L.os[i][4 * h + c] = y[c];
+      __syncthreads();
+      f32x4 t1;
+#pragma unroll
+      for (int c = 0; c < HD; ++c) {
+        const int o = 4 * h + c;
+        float a = b1s[o];
+#pragma unroll
+        for (int e = 0; e < E; ++e) a += L.os[i][e] * w1[o * E + e];
+        t1[c] = valid ? a : 0.f;
+      }
+      if (valid) *reinterpret_cast<f32x4*>(bf.T1 + ((size_t)cell * S + i) * E + 4 * h) = t1;
+      // sums over the cell's 16 tokens (the lanes of one head group), then over the iterations of this wave
+#pragma unroll
+      for (int c = 0; c < HD; ++c) {
+        double s1 = (double)t1[c], s2 = (double)t1[c] * (double)t1[c];
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+          s1 += __shfl_xor(s1, off, 64);
+          s2 += __shfl_xor(s2, off, 64);
+        }
+        if (i == 0) {
+          wsum[wave][4 * h + c] += s1;
+          wsum[wave][16 + 4 * h + c] += s2;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (POST && threadIdx.x < 32) {
+    const int s = threadIdx.x;
+    bf.stat_out[(size_t)blockIdx.x * 32 + s] = ((wsum[0][s] + wsum[1][s]) + wsum[2][s]) + wsum[3][s];
   }
 }
 
@@ -199,7 +352,9 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(float* __restrict__ dX, f
     const int cell = valid ? cell_raw : n_cells - 1;
     const float vscale = valid ? 1.f : 0.f;
     Fwd f;
-    forward_core(f, X, keep, W, LF, cell, i, h);
+    f32x4 xown;
+    load_token(f, xown, X, cell, i, h);
+    forward_core(f, xown, keep, W, LF, cell, i, h);
 
     // ---- LayerNorm backward (features 4h..4h+3 of token i) ----
     const f32x4 dy4 = *reinterpret_cast<const f32x4*>(dY + ((size_t)cell * S + i) * E + 4 * h);
@@ -720,6 +875,35 @@ extern "C" int cg_attn_ln_fwd(float* Y, const float* X, const float* keep, const
   } else {
     launch_gen_fwd<32>(Y, X, keep, params, n_cells, heads, st);
   }
+  return cg_launch_status();
+}
+
+extern "C" int cg_attn_block_blocks(int n_cells) {
+  int nb = (n_cells + 3) / 4;
+  if (nb > 1024) nb = 1024;
+  return nb < 1 ? 1 : nb;
+}
+
+extern "C" int cg_attn_block_fwd(float* Y, float* Xres, const float* T2, const float* Xin, const double* stat_in,
+                                 int n_stat_in, const float* gamma, const float* beta, float eps, float* mean_out,
+                                 float* invstd_out, float* running_mean, float* running_var, float momentum,
+                                 const float* keep, const float* params, int n_cells, int E_, int heads,
+                                 float* T1_next, double* stat_next, const float* W1_next, const float* b1_next,
+                                 void* stream) {
+  if (!Y || !Xres || !T2 || !Xin || !stat_in || !gamma || !beta || !mean_out || !invstd_out || !params ||
+      n_cells <= 0 || n_stat_in <= 0)
+    return CG_ERR_BAD_ARG;
+  if (!fused_16x4(E_, heads)) return CG_ERR_UNSUPPORTED;
+  if ((((uintptr_t)Y | (uintptr_t)Xres | (uintptr_t)T2 | (uintptr_t)Xin | (uintptr_t)keep | (uintptr_t)T1_next) % 16) != 0)
+    return CG_ERR_BAD_ARG;
+  if (T1_next && (!stat_next || !W1_next || !b1_next)) return CG_ERR_BAD_ARG;
+  const int nb = cg_attn_block_blocks(n_cells);
+  const int iters = (n_cells + nb * 4 - 1) / (nb * 4);
+  BlockFuse bf{T2, Xin, stat_in, n_stat_in, gamma, beta, eps, mean_out, invstd_out, running_mean, running_var, momentum,
+               Xres, n_cells * S, T1_next, stat_next, W1_next, b1_next};
+  hipStream_t st = (hipStream_t)stream;
+  if (T1_next) hipLaunchKernelGGL(attn_block_fwd_kernel<true>, dim3(nb), dim3(256), 0, st, Y, keep, params, n_cells, iters, bf);
+  else hipLaunchKernelGGL(attn_block_fwd_kernel<false>, dim3(nb), dim3(256), 0, st, Y, keep, params, n_cells, iters, bf);
   return cg_launch_status();
 }
 

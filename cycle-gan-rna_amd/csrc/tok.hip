@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(TB) tok_bn_lin_fwd(float* R, float* T2, double
                                                      const double* stat_in, const float* gamma, const float* beta,
                                                      float eps, float* mean_out, float* invstd_out, float* rmean,
                                                      float* rvar, float momentum, const float* W2, const float* b2,
-                                                     int n_tok) {
+                                                     int n_tok, int n_stat_in) {
   __shared__ float wl[TD * TD], bl[TD], tile[2 * TB * LS];
   __shared__ double red[4 * 32], tot[32];
   __shared__ BnCols bc;
@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(TB) tok_bn_lin_fwd(float* R, float* T2, double
   stage_weights(wl, bl, W2, b2);
   Row t1, r, t2;
   load_row(t1, T1, tok, ok);
-  total_stats(tot, stat_in, nblk, red);
+  total_stats(tot, stat_in, n_stat_in, red);      // as many partials as the kernel that wrote t1 had workgroups
   bn_fwd_cols(bc, tot, n_tok, eps, mean_out, invstd_out, rmean, rvar, momentum);
 #pragma unroll
   for (int c = 0; c < TD; ++c) {
@@ -383,7 +383,20 @@ extern "C" int cg_tok_bn_lin_fwd(float* R, float* T2, double* stat_out, const fl
       n_tok <= 0 || !aligned16(R) || !aligned16(T2) || !aligned16(T1))
     return CG_ERR_BAD_ARG;
   hipLaunchKernelGGL(tok_bn_lin_fwd, dim3(cg_tok_blocks(n_tok)), dim3(TB), 0, ST, R, T2, stat_out, T1, stat_in, gamma,
-                     beta, eps, mean_out, invstd_out, running_mean, running_var, momentum, W2, b2, n_tok);
+                     beta, eps, mean_out, invstd_out, running_mean, running_var, momentum, W2, b2, n_tok,
+                     cg_tok_blocks(n_tok));
+  return cg_launch_status();
+}
+
+extern "C" int cg_tok_bn_lin_fwd_from(float* R, float* T2, double* stat_out, const float* T1, const double* stat_in,
+                                      int n_stat_in, const float* gamma, const float* beta, float eps, float* mean_out,
+                                      float* invstd_out, float* running_mean, float* running_var, float momentum,
+                                      const float* W2, const float* b2, int n_tok, void* stream) {
+  if (!R || !T2 || !stat_out || !T1 || !stat_in || !gamma || !beta || !mean_out || !invstd_out || !W2 || !b2 ||
+      n_tok <= 0 || n_stat_in <= 0 || !aligned16(R) || !aligned16(T2) || !aligned16(T1))
+    return CG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(tok_bn_lin_fwd, dim3(cg_tok_blocks(n_tok)), dim3(TB), 0, ST, R, T2, stat_out, T1, stat_in, gamma,
+                     beta, eps, mean_out, invstd_out, running_mean, running_var, momentum, W2, b2, n_tok, n_stat_in);
   return cg_launch_status();
 }
 

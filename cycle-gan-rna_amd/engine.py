@@ -236,8 +236,12 @@ class GenPass:
         self.u = Z(T, D)
         self.rb_stats = [((Z(D), Z(D)), (Z(D), Z(D))) for _ in range(self.nb)]
         self.keep = [None] * self.nb
+        # 16-wide tokens with 4 heads: the block's last step, the attention and the next block's first step in one launch
+        self.fused_block = self.fused_tok and hasattr(ops, "attn_block_ok") and ops.attn_block_ok(self.D, self.heads)
         if self.fused_tok:
             nblk = max(ops.tok_blocks(T), 1)
+            if self.fused_block:
+                nblk = max(nblk, ops.attn_block_blocks(B))
             self.tok_stat = [Z(nblk * 32, dtype=torch.float64) for _ in range(4)]     # per-workgroup column sums
             self.tok_wpart = [Z(nblk * 256), Z(nblk * 256)]                           # per-workgroup 16x16 weight grads
         self.dec_in = Z(B, L + self.E)
@@ -364,6 +368,29 @@ class GenPass:
                 ops.axpby(y, 1.0, zin, 1.0, u)
                 self.net.nbt[pre + ".0.block.1.num_batches_tracked"] += 1
                 self.net.nbt[pre + ".0.block.4.num_batches_tracked"] += 1
+            elif train and self.fused_block:
+                # two launches per block: BatchNorm+ReLU+Linear | BatchNorm+residual, attention+LayerNorm and the next
+                # block's first Linear (the first block's own first Linear is a launch of its own)
+                sa, sb = self.tok_stat[0], self.tok_stat[1]
+                n_cells_blocks = ops.attn_block_blocks(b)
+                if bi == 0:
+                    ops.tok_lin_fwd(t1, sa, zin, W1, c1)
+                    ops.tok_bn_lin_fwd(r, t2, sb, t1, sa, g1, b1, s1[0], s1[1], rm1, rv1, W2, c2)
+                else:
+                    ops.tok_bn_lin_fwd_from(r, t2, sb, t1, sa, n_cells_blocks, g1, b1, s1[0], s1[1], rm1, rv1, W2, c2)
+                self.net.nbt[pre + ".0.block.1.num_batches_tracked"] += 1
+                self.net.nbt[pre + ".0.block.4.num_batches_tracked"] += 1
+                if all_keep is not None:
+                    self.keep[bi] = all_keep[bi]
+                else:
+                    self.keep[bi] = noise.keep((b * self.heads, SEQ_LEN, SEQ_LEN), 0.1)
+                nxt = None
+                if bi + 1 < self.nb:
+                    npre = f"residual_attention_blocks.{bi + 1}"
+                    nxt = (self.t1[bi + 1][:t], sa, P[npre + ".0.block.0.weight"], P[npre + ".0.block.0.bias"])
+                ops.attn_block_fwd(self.z[bi + 1][:b].view(t, self.D), y, t2, zin, sb, g2, b2, s2[0], s2[1], rm2, rv2,
+                                   self.keep[bi], self._attn("p", bi), self.heads, nxt=nxt)
+                continue
             elif train:     # three fused launches: Linear | BatchNorm+ReLU+Linear | BatchNorm+residual
                 sa, sb = self.tok_stat[0], self.tok_stat[1]
                 ops.tok_lin_fwd(t1, sa, zin, W1, c1)

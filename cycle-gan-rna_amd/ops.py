@@ -717,6 +717,41 @@ class HipOps:
                                               _ptr(beta), eps, _ptr(mean), _ptr(invstd), _ptr(rmean), _ptr(rvar),
                                               momentum, _ptr(W2), _ptr(b2), n, self._stream()), "cg_tok_bn_lin_fwd")
 
+    def attn_block_blocks(self, n_cells):
+        return self.lib.cg_attn_block_blocks(n_cells)
+
+    def tok_bn_lin_fwd_from(self, R, T2, stat_out, T1, stat_in, n_stat_in, gamma, beta, mean, invstd, rmean, rvar, W2, b2,
+                            eps=1e-5, momentum=0.1):
+        """tok_bn_lin_fwd whose input statistics are n_stat_in partials (written by attn_block_fwd)."""
+        n = T1.shape[0]
+        assert all(t.shape == (n, 16) and t.is_contiguous() for t in (R, T2, T1))
+        assert stat_out.numel() >= self.tok_blocks(n) * 32 and stat_in.numel() >= n_stat_in * 32
+        _lib.check(self.lib.cg_tok_bn_lin_fwd_from(_ptr(R), _ptr(T2), _ptr(stat_out), _ptr(T1), _ptr(stat_in), n_stat_in,
+                                                   _ptr(gamma), _ptr(beta), eps, _ptr(mean), _ptr(invstd), _ptr(rmean),
+                                                   _ptr(rvar), momentum, _ptr(W2), _ptr(b2), n, self._stream()),
+                   "cg_tok_bn_lin_fwd_from")
+
+    def attn_block_ok(self, E, heads):
+        """Is there a one-launch form of (BatchNorm + residual, attention + LayerNorm, next block's first Linear)?"""
+        return E == 16 and heads == 4 and not os.environ.get("CGRNA_NO_BLOCK_FUSION")
+
+    def attn_block_fwd(self, Y, Xres, T2, Xin, stat_in, gamma, beta, mean, invstd, rmean, rvar, keep, params, heads,
+                       nxt=None, eps=1e-5, momentum=0.1):
+        """Xres = Xin + bn2(T2); Y = LayerNorm(Xres + attention(Xres)); nxt = (T1, stat_out, W1, b1) of the next block:
+        T1 = Y W1^T + b1 and attn_block_blocks(n_cells) partial sums of T1, T1^2 into stat_out."""
+        n, E = T2.shape
+        n_cells = n // 16
+        assert all(t.shape == (n, E) and t.is_contiguous() for t in (Y, Xres, T2, Xin))
+        assert params.numel() == attn_nparam(E) and stat_in.numel() >= self.tok_blocks(n) * 32
+        assert keep is None or (keep.is_contiguous() and keep.numel() == n_cells * heads * 256)
+        T1, so, W1, b1 = nxt if nxt is not None else (None, None, None, None)
+        assert nxt is None or (T1.shape == (n, E) and T1.is_contiguous() and so.numel() >= self.attn_block_blocks(n_cells) * 32)
+        st = self.lib.cg_attn_block_fwd(_ptr(Y), _ptr(Xres), _ptr(T2), _ptr(Xin), _ptr(stat_in), self.tok_blocks(n),
+                                        _ptr(gamma), _ptr(beta), eps, _ptr(mean), _ptr(invstd), _ptr(rmean), _ptr(rvar),
+                                        momentum, _ptr(keep), _ptr(params), n_cells, E, heads, _ptr(T1), _ptr(so),
+                                        _ptr(W1), _ptr(b1), self._stream())
+        _lib.check(st, "cg_attn_block_fwd")
+
     def tok_bn_res_fwd(self, Y, T2, stat_in, gamma, beta, mean, invstd, rmean, rvar, X, eps=1e-5, momentum=0.1):
         n = T2.shape[0]
         assert all(t.shape == (n, 16) and t.is_contiguous() for t in (Y, T2, X))

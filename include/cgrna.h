@@ -519,6 +519,29 @@ int cg_adam_amsgrad(float* p, const float* g, float* m, float* v, float* vmax, s
 int cg_attn_ln_fwd(float* Y, const float* X, const float* keep, const float* params, int n_cells, int E, int heads,
                    void* stream);
 /*
+ * One residual-attention block of the bottleneck (GAN_functions.py:142-145: ResidualBlock :54-68, then
+ * GeneSelfAttention :28-36) from the ResidualBlock's second BatchNorm on, in one launch, for E = 16 with 4 heads
+ * (CG_ERR_UNSUPPORTED otherwise): what cg_tok_bn_res_fwd and cg_attn_ln_fwd do one after the other, and - when
+ * T1_next is not NULL - cg_tok_lin_fwd of the NEXT block:
+ *   Xres = Xin + bn2(T2)            (stat_in: the n_stat_in partial column sums of T2, T2^2 that cg_tok_bn_lin_fwd wrote;
+ *                                    mean_out / invstd_out / running statistics as cg_tok_bn_res_fwd)
+ *   Y = LayerNorm(Xres + attention(Xres))
+ *   T1_next = Y W1_next^T + b1_next; stat_next <- cg_attn_block_blocks(n_cells) x 32 partial sums of T1_next, T1_next^2
+ * cg_tok_bn_lin_fwd_from is cg_tok_bn_lin_fwd reading n_stat_in partials (here: cg_attn_block_blocks(n_cells)) instead
+ * of cg_tok_blocks(n_tok).  Two launches per block instead of four; Xres and T1_next are the bits of the separate
+ * launches, the statistics of T1_next differ from theirs in the order of additions only.
+ */
+int cg_attn_block_blocks(int n_cells);
+int cg_attn_block_fwd(float* Y, float* Xres, const float* T2, const float* Xin, const double* stat_in, int n_stat_in,
+                      const float* gamma, const float* beta, float eps, float* mean_out, float* invstd_out,
+                      float* running_mean, float* running_var, float momentum, const float* keep, const float* params,
+                      int n_cells, int E, int heads, float* T1_next, double* stat_next, const float* W1_next,
+                      const float* b1_next, void* stream);
+int cg_tok_bn_lin_fwd_from(float* R, float* T2, double* stat_out, const float* T1, const double* stat_in, int n_stat_in,
+                           const float* gamma, const float* beta, float eps, float* mean_out, float* invstd_out,
+                           float* running_mean, float* running_var, float momentum, const float* W2, const float* b2,
+                           int n_tok, void* stream);
+/*
  * Backward of cg_attn_ln_fwd; the forward is recomputed from X and keep, so no
  * activations are saved.  dX receives the input gradient; parameter gradients
  * are summed per workgroup into `wpart` (cg_attn_bwd_ws(n_cells, E, heads)

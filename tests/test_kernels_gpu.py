@@ -979,3 +979,59 @@ def test_gemm_split_k_combined_in_the_kernel_under_load(ops):
     assert bad == 0, f"{bad} words differ from the two-launch product"
     assert int(ws[-ops.WS_COUNTER_FLOATS:].view(torch.int32).abs().max()) == 0
     assert not os.environ.get("CGRNA_GEMM_SEPARATE_REDUCE"), "the test compared the two-launch form with itself"
+
+
+@pytest.mark.parametrize("n_cells,with_next,train", [(512, True, True), (512, False, True), (37, True, True), (3, True, False),
+                                                     (4100, True, True)])
+def test_attention_block_in_one_launch(ops, n_cells, with_next, train):
+    """cg_attn_block_fwd (+ cg_tok_bn_lin_fwd_from) against the launches it replaces - cg_tok_bn_res_fwd, cg_attn_ln_fwd
+    and the next block's cg_tok_lin_fwd: the residual sum, the block's output, the BatchNorm statistics it saves and
+    updates and the next block's pre-activation are the same bits; the column sums of that pre-activation are added in
+    another order (relative 1e-12 in float64), and the BatchNorm + Linear that consumes them agrees to float32
+    rounding."""
+    heads, n = 4, n_cells * 16
+    Z = lambda *s: torch.zeros(*s, device="cuda")  # noqa: E731
+    Zd = lambda *s: torch.zeros(*s, dtype=torch.float64, device="cuda")  # noqa: E731
+    Xin, T1 = dev(rnd(n, 16, seed=1)), dev(rnd(n, 16, seed=2))
+    W2, b2 = dev(rnd(16, 16, seed=3) * 0.4), dev(rnd(16, seed=5))
+    W1n, b1n = dev(rnd(16, 16, seed=13) * 0.4), dev(rnd(16, seed=14))
+    g1, be1, g2, be2 = dev(rnd(16, seed=6) + 1.5), dev(rnd(16, seed=7)), dev(rnd(16, seed=8) + 1.5), dev(rnd(16, seed=9))
+    rm, rv = dev(rnd(16, seed=10)), dev(rnd(16, seed=11).abs() + 0.5)
+    params = rnd(ATTN_NPARAM, seed=2) * 0.3
+    params[1088:1104] += 1.0
+    params = dev(params)
+    keep = dev((torch.rand(n_cells * heads, 16, 16, generator=torch.Generator().manual_seed(3)) < 0.9).float() / 0.9) if train else None
+    nb_tok, nb_att = ops.tok_blocks(n), ops.attn_block_blocks(n_cells)
+    # the block's first two launches are common to both forms
+    s0, s1 = Zd(nb_tok * 32), Zd(nb_tok * 32)
+    R, T2 = Z(n, 16), Z(n, 16)
+    ops.tok_lin_fwd(T1, s0, Xin, W2, b2)        # any pre-activation with its column sums
+    ops.tok_bn_lin_fwd(R, T2, s1, T1, s0, g1, be1, Z(16), Z(16), rm.clone(), rv.clone(), W2, b2)
+    # separate launches
+    Ys, Xs, T1s, m2s, i2s, rm2s, rv2s = Z(n, 16), Z(n, 16), Z(n, 16), Z(16), Z(16), rm.clone(), rv.clone()
+    sn_s = Zd(nb_tok * 32)
+    ops.tok_bn_res_fwd(Xs, T2, s1, g2, be2, m2s, i2s, rm2s, rv2s, Xin)
+    ops.attn_fwd(Ys, Xs, keep, params, heads)
+    ops.tok_lin_fwd(T1s, sn_s, Ys, W1n, b1n)
+    # one launch
+    Yf, Xf, T1f, m2f, i2f, rm2f, rv2f = Z(n, 16), Z(n, 16), Z(n, 16), Z(16), Z(16), rm.clone(), rv.clone()
+    sn_f = Zd(max(nb_att, nb_tok) * 32)
+    ops.attn_block_fwd(Yf, Xf, T2, Xin, s1, g2, be2, m2f, i2f, rm2f, rv2f, keep, params, heads,
+                       nxt=(T1f, sn_f, W1n, b1n) if with_next else None)
+    torch.cuda.synchronize()
+    for a, b_, what in ((Xf, Xs, "residual sum"), (Yf, Ys, "block output"), (m2f, m2s, "mean"), (i2f, i2s, "invstd"),
+                        (rm2f, rm2s, "running mean"), (rv2f, rv2s, "running var")):
+        assert torch.equal(a, b_), what
+    if not with_next:
+        assert float(T1f.abs().max()) == 0.0
+        return
+    assert torch.equal(T1f, T1s)
+    tot_s = sn_s.view(nb_tok, 32).sum(0)
+    tot_f = sn_f[:nb_att * 32].view(nb_att, 32).sum(0)
+    assert float(((tot_f - tot_s).abs() / tot_s.abs().clamp_min(1e-30)).max()) < 1e-11
+    Rs, T2s, Rf, T2f = Z(n, 16), Z(n, 16), Z(n, 16), Z(n, 16)
+    so_s, so_f = Zd(nb_tok * 32), Zd(nb_tok * 32)
+    ops.tok_bn_lin_fwd(Rs, T2s, so_s, T1s, sn_s, g1, be1, Z(16), Z(16), rm.clone(), rv.clone(), W2, b2)
+    ops.tok_bn_lin_fwd_from(Rf, T2f, so_f, T1f, sn_f, nb_att, g1, be1, Z(16), Z(16), rm.clone(), rv.clone(), W2, b2)
+    close(Rf, Rs.cpu(), 1e-6, "consumer of the fused statistics: R")
+    close(T2f, T2s.cpu(), 1e-6, "consumer of the fused statistics: T2")
