@@ -91,6 +91,8 @@ SIGNATURES = {
     "cg_adam_amsgrad": ([P, P, P, P, P, Z, P, F, F, F, P, P], I),
     "cg_attn_ln_fwd": ([P, P, P, P, I, I, I, P], I),
     "cg_attn_block_blocks": ([I], I),
+    "cg_attn_block_bwd": ([P, P, P, P, P, P, P, I, I, I, I, P, P, P, P, P], I),
+    "cg_tok_bwd_mid_from": ([P, P, P, P, P, P, P, P, P, P, I, P, P, P, P, P, P, I, P], I),
     "cg_attn_block_fwd": ([P, P, P, P, P, I, P, P, F, P, P, P, P, F, P, P, I, I, I, P, P, P, P, P], I),
     "cg_tok_bn_lin_fwd_from": ([P, P, P, P, P, I, P, P, F, P, P, P, P, F, P, P, I, P], I),
     "cg_attn_bwd_blocks": ([I], I),

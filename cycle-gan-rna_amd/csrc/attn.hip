@@ -324,14 +324,32 @@ struct WaveLdsBwd {
   float cat[S][CATW];        // per token: dqkv(48) | ds(16) | dy*xhat(16) | dy(16)
 };
 
+// STATS: the first step of the token ResidualBlock's backward (tok_bn_bwd_stats in tok.hip) in the same launch: with
+// g = dX, the gradient this kernel hands to that block's second BatchNorm, the per-workgroup sums of g and
+// g * xhat2, xhat2 = (T2 - mean2) * invstd2, in float64 -> stat_out[gridDim.x][32] (fixed order of additions).
+struct BwdStats {
+  const float* T2; const float* mean2; const float* invstd2; double* stat_out;
+};
+
+template <bool STATS>
 __global__ void __launch_bounds__(256) attn_bwd_kernel(float* __restrict__ dX, float* __restrict__ wpart,
                                                        const float* __restrict__ dY, const float* __restrict__ X,
                                                        const float* __restrict__ keep,
-                                                       const float* __restrict__ params, int n_cells, int iters) {
+                                                       const float* __restrict__ params, int n_cells, int iters,
+                                                       BwdStats bs) {
   __shared__ __align__(16) float W[NPARAM];
   __shared__ __align__(16) WaveLdsFwd ldsf[4];
   __shared__ __align__(16) WaveLdsBwd ldsb[4];
+  __shared__ double wsum[4][32];
+  __shared__ float smean[E], sinv[E];
   for (int t = threadIdx.x; t < NPARAM; t += 256) W[t] = params[t];
+  if (STATS) {
+    if (threadIdx.x < 128) wsum[threadIdx.x >> 5][threadIdx.x & 31] = 0.0;
+    if (threadIdx.x < E) {
+      smean[threadIdx.x] = bs.mean2[threadIdx.x];
+      sinv[threadIdx.x] = bs.invstd2[threadIdx.x];
+    }
+  }
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 15, h = lane >> 4;
@@ -450,6 +468,24 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(float* __restrict__ dX, f
         for (int c = 0; c < HD; ++c) dx[c] += g * W[OFF_WIN + r * E + 4 * h + c];
       }
       if (valid) *reinterpret_cast<f32x4*>(dX + ((size_t)cell * S + i) * E + 4 * h) = dx;
+      if (STATS) {
+        const f32x4 t2 = *reinterpret_cast<const f32x4*>(bs.T2 + ((size_t)cell * S + i) * E + 4 * h);
+#pragma unroll
+        for (int c = 0; c < HD; ++c) {
+          const float g = valid ? dx[c] : 0.f;
+          const float xh = valid ? (t2[c] - smean[4 * h + c]) * sinv[4 * h + c] : 0.f;
+          double s1 = (double)g, s2 = (double)g * (double)xh;
+#pragma unroll
+          for (int off = 1; off < 16; off <<= 1) {      // over the cell's 16 tokens (the lanes of one head group)
+            s1 += __shfl_xor(s1, off, 64);
+            s2 += __shfl_xor(s2, off, 64);
+          }
+          if (i == 0) {
+            wsum[wave][4 * h + c] += s1;
+            wsum[wave][16 + 4 * h + c] += s2;
+          }
+        }
+      }
     }
     // ---- parameter gradients (invalid cells contribute zeros: dy was zeroed) ----
     {
@@ -494,6 +530,10 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(float* __restrict__ dX, f
   float* outp = wpart + (size_t)blockIdx.x * NPARAM;
   for (int t = threadIdx.x; t < NPARAM; t += 256) {
     outp[t] = red[t] + red[NPARAM + t] + red[2 * NPARAM + t] + red[3 * NPARAM + t];
+  }
+  if (STATS && threadIdx.x < 32) {
+    const int s = threadIdx.x;
+    bs.stat_out[(size_t)blockIdx.x * 32 + s] = ((wsum[0][s] + wsum[1][s]) + wsum[2][s]) + wsum[3][s];
   }
 }
 
@@ -878,6 +918,24 @@ extern "C" int cg_attn_ln_fwd(float* Y, const float* X, const float* keep, const
   return cg_launch_status();
 }
 
+extern "C" int cg_attn_block_bwd(float* dX, float* dparams, float* wpart, const float* dY, const float* X,
+                                 const float* keep, const float* params, int n_cells, int E_, int heads, int accumulate,
+                                 const float* T2, const float* mean2, const float* invstd2, double* stat_out,
+                                 void* stream) {
+  if (!dX || !dparams || !wpart || !dY || !X || !params || !T2 || !mean2 || !invstd2 || !stat_out || n_cells <= 0)
+    return CG_ERR_BAD_ARG;
+  if (!fused_16x4(E_, heads)) return CG_ERR_UNSUPPORTED;
+  if ((((uintptr_t)dX | (uintptr_t)dY | (uintptr_t)X | (uintptr_t)keep | (uintptr_t)T2) % 16) != 0) return CG_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int nb = cg_attn_bwd_blocks(n_cells);
+  const int iters = (n_cells + nb * 4 - 1) / (nb * 4);
+  hipLaunchKernelGGL(attn_bwd_kernel<true>, dim3(nb), dim3(256), 0, st, dX, wpart, dY, X, keep, params, n_cells, iters,
+                     BwdStats{T2, mean2, invstd2, stat_out});
+  hipLaunchKernelGGL(attn_param_reduce_kernel, dim3((NPARAM + 31) / 32), dim3(256), 0, st, dparams, wpart, nb, accumulate,
+                     NPARAM);
+  return cg_launch_status();
+}
+
 extern "C" int cg_attn_block_blocks(int n_cells) {
   int nb = (n_cells + 3) / 4;
   if (nb > 1024) nb = 1024;
@@ -917,7 +975,8 @@ extern "C" int cg_attn_ln_bwd(float* dX, float* dparams, float* wpart, const flo
   if (fused_16x4(E_, heads)) {
     const int nb = cg_attn_bwd_blocks(n_cells);
     const int iters = (n_cells + nb * 4 - 1) / (nb * 4);
-    hipLaunchKernelGGL(attn_bwd_kernel, dim3(nb), dim3(256), 0, st, dX, wpart, dY, X, keep, params, n_cells, iters);
+    hipLaunchKernelGGL(attn_bwd_kernel<false>, dim3(nb), dim3(256), 0, st, dX, wpart, dY, X, keep, params, n_cells, iters,
+                       BwdStats{nullptr, nullptr, nullptr, nullptr});
     hipLaunchKernelGGL(attn_param_reduce_kernel, dim3((NPARAM + 31) / 32), dim3(256), 0, st, dparams, wpart, nb,
                        accumulate, NPARAM);
   } else if (E_ == 4) {

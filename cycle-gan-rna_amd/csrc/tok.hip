@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(TB) tok_bwd_mid(float* G1, double* stat_out, f
                                                   float* dbeta2, const float* dY, const float* T2, const float* R,
                                                   const float* T1, const double* stat_in, const float* mean2,
                                                   const float* invstd2, const float* gamma2, const float* W2,
-                                                  const float* mean1, const float* invstd1, int n_tok) {
+                                                  const float* mean1, const float* invstd1, int n_tok, int n_stat_in) {
   __shared__ float wl[TD * TD], tile[2 * TB * LS];
   __shared__ double red[4 * 32], tot[32];
   TOK_COMMON
@@ -293,7 +293,7 @@ __global__ void __launch_bounds__(TB) tok_bwd_mid(float* G1, double* stat_out, f
   load_row(t2, T2, tok, ok);
   load_row(r, R, tok, ok);
   load_row(t1, T1, tok, ok);
-  total_stats(tot, stat_in, nblk, red);
+  total_stats(tot, stat_in, n_stat_in, red);      // as many partials as the kernel that wrote them had workgroups
 #pragma unroll
   for (int c = 0; c < TD; ++c) xh.v[c] = (t2.v[c] - mean2[c]) * invstd2[c];
   bn_bwd_row(dt2, g, xh, tot, n_tok, invstd2, gamma2, dgamma2, dbeta2);
@@ -429,7 +429,21 @@ extern "C" int cg_tok_bwd_mid(float* G1, double* stat_out, float* wpart, float* 
     return CG_ERR_BAD_ARG;
   if (!aligned16(G1) || !aligned16(dY) || !aligned16(T2) || !aligned16(R) || !aligned16(T1)) return CG_ERR_BAD_ARG;
   hipLaunchKernelGGL(tok_bwd_mid, dim3(cg_tok_blocks(n_tok)), dim3(TB), 0, ST, G1, stat_out, wpart, dgamma2, dbeta2, dY,
-                     T2, R, T1, stat_in, mean2, invstd2, gamma2, W2, mean1, invstd1, n_tok);
+                     T2, R, T1, stat_in, mean2, invstd2, gamma2, W2, mean1, invstd1, n_tok, cg_tok_blocks(n_tok));
+  return cg_launch_status();
+}
+
+extern "C" int cg_tok_bwd_mid_from(float* G1, double* stat_out, float* wpart, float* dgamma2, float* dbeta2,
+                                   const float* dY, const float* T2, const float* R, const float* T1,
+                                   const double* stat_in, int n_stat_in, const float* mean2, const float* invstd2,
+                                   const float* gamma2, const float* W2, const float* mean1, const float* invstd1,
+                                   int n_tok, void* stream) {
+  if (!G1 || !stat_out || !wpart || !dY || !T2 || !R || !T1 || !stat_in || !mean2 || !invstd2 || !gamma2 || !W2 ||
+      !mean1 || !invstd1 || n_tok <= 0 || n_stat_in <= 0)
+    return CG_ERR_BAD_ARG;
+  if (!aligned16(G1) || !aligned16(dY) || !aligned16(T2) || !aligned16(R) || !aligned16(T1)) return CG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(tok_bwd_mid, dim3(cg_tok_blocks(n_tok)), dim3(TB), 0, ST, G1, stat_out, wpart, dgamma2, dbeta2, dY,
+                     T2, R, T1, stat_in, mean2, invstd2, gamma2, W2, mean1, invstd1, n_tok, n_stat_in);
   return cg_launch_status();
 }
 

@@ -241,7 +241,7 @@ class GenPass:
         if self.fused_tok:
             nblk = max(ops.tok_blocks(T), 1)
             if self.fused_block:
-                nblk = max(nblk, ops.attn_block_blocks(B))
+                nblk = max(nblk, ops.attn_block_blocks(B), ops.attn_bwd_blocks(B))
             self.tok_stat = [Z(nblk * 32, dtype=torch.float64) for _ in range(4)]     # per-workgroup column sums
             self.tok_wpart = [Z(nblk * 256), Z(nblk * 256)]                           # per-workgroup 16x16 weight grads
         self.dec_in = Z(B, L + self.E)
@@ -518,17 +518,28 @@ class GenPass:
             pre = f"residual_attention_blocks.{bi}"
             (s1, s2) = self.rb_stats[bi]
             dy = self.dz[1 - cur][:b].view(t, self.D)
-            ops.attn_bwd(dy, self._attn("g", bi), self.attn_ws, dz, self.y[bi][:t], self.keep[bi], self._attn("p", bi),
-                         self.heads, True)
             zin = self.z[bi][:b].view(t, self.D)
+            if self.fused_block:        # the attention's backward also sums what the BatchNorm backward below needs
+                s3 = self.tok_stat[2]
+                ops.attn_block_bwd(dy, self._attn("g", bi), self.attn_ws, dz, self.y[bi][:t], self.keep[bi],
+                                   self._attn("p", bi), self.heads, True, self.t2[bi][:t], s2[0], s2[1], s3)
+            else:
+                ops.attn_bwd(dy, self._attn("g", bi), self.attn_ws, dz, self.y[bi][:t], self.keep[bi], self._attn("p", bi),
+                             self.heads, True)
             if self.fused_tok:
                 s3, s4 = self.tok_stat[2], self.tok_stat[3]
                 wp2, wp1 = self.tok_wpart
                 g1buf = self.d16[0][:t]
-                ops.tok_bn_bwd_stats(s3, dy, self.t2[bi][:t], s2[0], s2[1])
-                ops.tok_bwd_mid(g1buf, s4, wp2, G[pre + ".0.block.4.weight"], G[pre + ".0.block.4.bias"], dy,
-                                self.t2[bi][:t], self.r[bi][:t], self.t1[bi][:t], s3, s2[0], s2[1],
-                                P[pre + ".0.block.4.weight"], P[pre + ".0.block.3.weight"], s1[0], s1[1])
+                mid = (self.t2[bi][:t], self.r[bi][:t], self.t1[bi][:t])
+                if self.fused_block:
+                    ops.tok_bwd_mid_from(g1buf, s4, wp2, G[pre + ".0.block.4.weight"], G[pre + ".0.block.4.bias"], dy,
+                                         *mid, s3, ops.attn_bwd_blocks(b), s2[0], s2[1],
+                                         P[pre + ".0.block.4.weight"], P[pre + ".0.block.3.weight"], s1[0], s1[1])
+                else:
+                    ops.tok_bn_bwd_stats(s3, dy, self.t2[bi][:t], s2[0], s2[1])
+                    ops.tok_bwd_mid(g1buf, s4, wp2, G[pre + ".0.block.4.weight"], G[pre + ".0.block.4.bias"], dy,
+                                    *mid, s3, s2[0], s2[1],
+                                    P[pre + ".0.block.4.weight"], P[pre + ".0.block.3.weight"], s1[0], s1[1])
                 ops.tok_bwd_in(dy, wp1, G[pre + ".0.block.1.weight"], G[pre + ".0.block.1.bias"], g1buf,
                                self.t1[bi][:t], zin, dy, s4, s1[0], s1[1], P[pre + ".0.block.1.weight"],
                                P[pre + ".0.block.0.weight"])

@@ -802,6 +802,32 @@ class HipOps:
         st = self.lib.cg_attn_ln_fwd(_ptr(Y), _ptr(X), _ptr(keep), _ptr(params), n_cells, E, heads, self._stream())
         _lib.check(st, "cg_attn_ln_fwd")
 
+    def attn_block_bwd(self, dX, dparams, ws, dY, X, keep, params, heads, accumulate, T2, mean2, invstd2, stat_out):
+        """attn_bwd + tok_bn_bwd_stats of the ResidualBlock below: attn_bwd_blocks(n_cells) partials into stat_out."""
+        E = X.shape[-1]
+        n_cells = X.numel() // (16 * E)
+        assert ws.numel() >= self.attn_bwd_ws(n_cells, E, heads) and dparams.numel() == attn_nparam(E)
+        assert X.is_contiguous() and dY.is_contiguous() and dX.is_contiguous() and T2.is_contiguous()
+        assert stat_out.numel() >= self.attn_bwd_blocks(n_cells) * 32
+        st = self.lib.cg_attn_block_bwd(_ptr(dX), _ptr(dparams), _ptr(ws), _ptr(dY), _ptr(X), _ptr(keep), _ptr(params),
+                                        n_cells, E, heads, int(accumulate), _ptr(T2), _ptr(mean2), _ptr(invstd2),
+                                        _ptr(stat_out), self._stream())
+        _lib.check(st, "cg_attn_block_bwd")
+
+    def attn_bwd_blocks(self, n_cells):
+        return self.lib.cg_attn_bwd_blocks(n_cells)
+
+    def tok_bwd_mid_from(self, G1, stat_out, wpart, dgamma2, dbeta2, dY, T2, R, T1, stat_in, n_stat_in, mean2, invstd2,
+                         gamma2, W2, mean1, invstd1):
+        n = dY.shape[0]
+        assert all(t.shape == (n, 16) and t.is_contiguous() for t in (G1, dY, T2, R, T1))
+        nb = self.tok_blocks(n)
+        assert stat_out.numel() >= nb * 32 and stat_in.numel() >= n_stat_in * 32 and wpart.numel() >= nb * 256
+        _lib.check(self.lib.cg_tok_bwd_mid_from(_ptr(G1), _ptr(stat_out), _ptr(wpart), _ptr(dgamma2), _ptr(dbeta2),
+                                                _ptr(dY), _ptr(T2), _ptr(R), _ptr(T1), _ptr(stat_in), n_stat_in,
+                                                _ptr(mean2), _ptr(invstd2), _ptr(gamma2), _ptr(W2), _ptr(mean1),
+                                                _ptr(invstd1), n, self._stream()), "cg_tok_bwd_mid_from")
+
     def attn_bwd_ws(self, n_cells, E=16, heads=4):
         n = self.lib.cg_attn_bwd_ws(n_cells, E, heads)
         if n < 0:

@@ -531,7 +531,20 @@ int cg_attn_ln_fwd(float* Y, const float* X, const float* keep, const float* par
  * of cg_tok_blocks(n_tok).  Two launches per block instead of four; Xres and T1_next are the bits of the separate
  * launches, the statistics of T1_next differ from theirs in the order of additions only.
  */
+/*
+ * cg_attn_block_bwd: cg_attn_ln_bwd that also takes the first step of the ResidualBlock's backward below it
+ * (cg_tok_bn_bwd_stats): with g = dX it writes cg_attn_bwd_blocks(n_cells) x 32 partial sums of g and
+ * g * (T2 - mean2) * invstd2 to stat_out, which cg_tok_bwd_mid_from (cg_tok_bwd_mid reading n_stat_in partials) adds
+ * up.  E = 16 with 4 heads only.
+ */
 int cg_attn_block_blocks(int n_cells);
+int cg_attn_block_bwd(float* dX, float* dparams, float* wpart, const float* dY, const float* X, const float* keep,
+                      const float* params, int n_cells, int E, int heads, int accumulate, const float* T2,
+                      const float* mean2, const float* invstd2, double* stat_out, void* stream);
+int cg_tok_bwd_mid_from(float* G1, double* stat_out, float* wpart, float* dgamma2, float* dbeta2, const float* dY,
+                        const float* T2, const float* R, const float* T1, const double* stat_in, int n_stat_in,
+                        const float* mean2, const float* invstd2, const float* gamma2, const float* W2,
+                        const float* mean1, const float* invstd1, int n_tok, void* stream);
 int cg_attn_block_fwd(float* Y, float* Xres, const float* T2, const float* Xin, const double* stat_in, int n_stat_in,
                       const float* gamma, const float* beta, float eps, float* mean_out, float* invstd_out,
                       float* running_mean, float* running_var, float momentum, const float* keep, const float* params,

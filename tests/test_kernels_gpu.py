@@ -1035,3 +1035,45 @@ def test_attention_block_in_one_launch(ops, n_cells, with_next, train):
     ops.tok_bn_lin_fwd_from(Rf, T2f, so_f, T1f, sn_f, nb_att, g1, be1, Z(16), Z(16), rm.clone(), rv.clone(), W2, b2)
     close(Rf, Rs.cpu(), 1e-6, "consumer of the fused statistics: R")
     close(T2f, T2s.cpu(), 1e-6, "consumer of the fused statistics: T2")
+
+
+@pytest.mark.parametrize("n_cells", [512, 37, 2000])
+def test_attention_block_backward_in_one_launch(ops, n_cells):
+    """cg_attn_block_bwd + cg_tok_bwd_mid_from against cg_attn_ln_bwd, cg_tok_bn_bwd_stats and cg_tok_bwd_mid: the
+    attention's input gradient and parameter gradients are the same bits, the sums for the BatchNorm backward agree
+    to float64 rounding (another order of additions), what that backward makes of them to float32 rounding."""
+    heads, n = 4, n_cells * 16
+    Z = lambda *s: torch.zeros(*s, device="cuda")  # noqa: E731
+    Zd = lambda *s: torch.zeros(*s, dtype=torch.float64, device="cuda")  # noqa: E731
+    X, dY = dev(rnd(n, 16, seed=1)), dev(rnd(n, 16, seed=4))
+    T2, R, T1 = dev(rnd(n, 16, seed=5)), dev(rnd(n, 16, seed=6).abs()), dev(rnd(n, 16, seed=7))
+    m2, i2, m1, i1 = dev(rnd(16, seed=8)), dev(rnd(16, seed=9).abs() + 0.5), dev(rnd(16, seed=10)), dev(rnd(16, seed=11).abs() + 0.5)
+    g2, W2 = dev(rnd(16, seed=12) + 1.5), dev(rnd(16, 16, seed=13) * 0.4)
+    params = rnd(ATTN_NPARAM, seed=2) * 0.3
+    params[1088:1104] += 1.0
+    params = dev(params)
+    keep = dev((torch.rand(n_cells * heads, 16, 16, generator=torch.Generator().manual_seed(3)) < 0.9).float() / 0.9)
+    nb_tok, nb_att = ops.tok_blocks(n), ops.attn_bwd_blocks(n_cells)
+    ws = torch.empty(ops.attn_bwd_ws(n_cells)).cuda()
+    out = {}
+    for form in ("separate", "fused"):
+        dX, dp = Z(n, 16), torch.ones(ATTN_NPARAM).cuda()
+        s3, s4 = Zd(max(nb_tok, nb_att) * 32), Zd(nb_tok * 32)
+        G1, wp2, dg2, db2 = Z(n, 16), Z(nb_tok * 256), Z(16), Z(16)
+        if form == "separate":
+            ops.attn_bwd(dX, dp, ws, dY, X, keep, params, heads, True)
+            ops.tok_bn_bwd_stats(s3, dX, T2, m2, i2)
+            ops.tok_bwd_mid(G1, s4, wp2, dg2, db2, dX, T2, R, T1, s3, m2, i2, g2, W2, m1, i1)
+            tot = s3[:nb_tok * 32].view(nb_tok, 32).sum(0)
+        else:
+            ops.attn_block_bwd(dX, dp, ws, dY, X, keep, params, heads, True, T2, m2, i2, s3)
+            ops.tok_bwd_mid_from(G1, s4, wp2, dg2, db2, dX, T2, R, T1, s3, nb_att, m2, i2, g2, W2, m1, i1)
+            tot = s3[:nb_att * 32].view(nb_att, 32).sum(0)
+        torch.cuda.synchronize()
+        out[form] = dict(dX=dX, dp=dp, tot=tot, G1=G1, wp2=wp2.view(nb_tok, 256).sum(0), dg2=dg2, db2=db2,
+                         s4=s4.view(nb_tok, 32).sum(0))
+    a, b_ = out["fused"], out["separate"]
+    assert torch.equal(a["dX"], b_["dX"]) and torch.equal(a["dp"], b_["dp"])
+    assert float(((a["tot"] - b_["tot"]).abs() / b_["tot"].abs().clamp_min(1e-30)).max()) < 1e-10
+    for k in ("G1", "wp2", "dg2", "db2", "s4"):
+        close(a[k], b_[k].cpu(), 2e-6, f"consumer of the fused sums: {k}")
