@@ -211,6 +211,39 @@ __global__ void interp_hidden_kernel(float* H, int ldh, const float* alpha, cons
   }
 }
 
+// The same with labels, tiled: a workgroup owns 64 columns x 32 rows and first puts its 64 rows of We and its 32
+// embedding differences into LDS - We's rows are 48 bytes at a stride of a whole first-layer row, and every thread of
+// a column used to fetch them again - so the dot products read LDS (row stride 33 floats: conflict-free).
+constexpr int IH_C = 64, IH_R = 32, IH_EMAX = 32;
+__global__ void __launch_bounds__(256) interp_hidden_tiled_kernel(float* H, int ldh, const float* alpha,
+                                                                  const float* emb, int lde, int E, const float* We,
+                                                                  int ldw, int M, int N) {
+  __shared__ float we[IH_C][IH_EMAX + 1], de[IH_R][IH_EMAX + 1], al[IH_R];
+  const int c0 = blockIdx.x * IH_C, r0 = blockIdx.y * IH_R;
+  for (int i = threadIdx.x; i < IH_C * E; i += 256) {
+    const int c = i / E, j = i - c * E;
+    we[c][j] = c0 + c < N ? We[(size_t)(c0 + c) * ldw + j] : 0.f;
+  }
+  for (int i = threadIdx.x; i < IH_R * E; i += 256) {
+    const int r = i / E, j = i - r * E, m = r0 + r;
+    de[r][j] = m < M ? emb[(size_t)(M + m) * lde + j] - emb[(size_t)m * lde + j] : 0.f;
+  }
+  if (threadIdx.x < IH_R) al[threadIdx.x] = r0 + (int)threadIdx.x < M ? alpha[r0 + threadIdx.x] : 0.f;
+  __syncthreads();
+  const int c = threadIdx.x & 63, col = c0 + c;
+  if (col >= N) return;
+  for (int r = threadIdx.x >> 6; r < IH_R; r += 4) {
+    const int m = r0 + r;
+    if (m >= M) break;
+    const float a = al[r];
+    float v = a * H[(size_t)m * ldh + col] + (1.f - a) * H[(size_t)(M + m) * ldh + col];
+    float d = 0.f;
+    for (int j = 0; j < E; ++j) d += de[r][j] * we[c][j];
+    v += a * d;
+    H[(size_t)(2 * M + m) * ldh + col] = v;
+  }
+}
+
 // The penalty's weight-gradient term vh0^T x_interp folded into the Wasserstein terms (see cg_gp_combine): in place,
 // D[m] += a_m VH[m] (real rows), D[M + m] += (1 - a_m) VH[m] (generated rows); AV[m] = a_m VH[m]; and, by the first
 // column block, dE[m] = emb[M + m] - emb[m].
@@ -252,6 +285,38 @@ __global__ void __launch_bounds__(256) gp_penalty_kernel(float* V, int ldv, floa
     const float v = k * UX[(size_t)m * ldu + c];
     V[(size_t)m * ldv + c] = v;
     if (V16) V16[(size_t)m * ldv + c] = f2bf(v);
+  }
+}
+
+// The same for rows of at most 256 * NV values: the row stays in registers between the norm and the scaling (one
+// read of UX instead of two; the squares are added in the same order).
+template <int NV>
+__global__ void __launch_bounds__(256) gp_penalty_regs_kernel(float* V, int ldv, float* rowpen, const float* UX, int ldu,
+                                                              float lam2_over_m, int G, u16* V16) {
+  __shared__ float lds[17];
+  const int m = blockIdx.x;
+  float u[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = threadIdx.x + 256 * i;
+    u[i] = UX[(size_t)m * ldu + min(c, G - 1)];
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i)
+    if ((int)threadIdx.x + 256 * i < G) s += u[i] * u[i];
+  s = block_sum<float>(s, lds, true);
+  const float n = sqrtf(s);
+  if (threadIdx.x == 0) rowpen[m] = (n - 1.f) * (n - 1.f);
+  const float k = n > 0.f ? lam2_over_m * (n - 1.f) / n : 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = threadIdx.x + 256 * i;
+    if (c < G) {
+      const float v = k * u[i];
+      V[(size_t)m * ldv + c] = v;
+      if (V16) V16[(size_t)m * ldv + c] = f2bf(v);
+    }
   }
 }
 
@@ -663,6 +728,11 @@ extern "C" int cg_interp_hidden(float* H, int ldh, const float* alpha, const flo
                                 const float* We, int ldw, int M, int N, void* stream) {
   if (!H || !alpha || M <= 0 || N <= 0 || ldh < N) return CG_ERR_BAD_ARG;
   if (emb && (!We || E <= 0 || lde < E || ldw < E)) return CG_ERR_BAD_ARG;
+  if (emb && E <= IH_EMAX) {
+    hipLaunchKernelGGL(interp_hidden_tiled_kernel, dim3((N + IH_C - 1) / IH_C, (M + IH_R - 1) / IH_R), dim3(256), 0, ST, H,
+                       ldh, alpha, emb, lde, E, We, ldw, M, N);
+    return cg_launch_status();
+  }
   Grid2 g = grid2(M, N);
   hipLaunchKernelGGL(interp_hidden_kernel, g.grid, g.block, 0, ST, H, ldh, alpha, emb, lde, E, We, ldw, M, N);
   return cg_launch_status();
@@ -682,8 +752,12 @@ extern "C" int cg_gp_combine(float* D, int ldd, const float* VH, int ldv, const 
 extern "C" int cg_gp_penalty(float* V, int ldv, float* rowpen, const float* UX, int ldu, float lambda_gp, int M, int G,
                              void* v_bf16, void* stream) {
   if (!V || !rowpen || !UX || M <= 0 || G <= 0 || ldv < G || ldu < G) return CG_ERR_BAD_ARG;
-  hipLaunchKernelGGL(gp_penalty_kernel, dim3(M), dim3(256), 0, ST, V, ldv, rowpen, UX, ldu, lambda_gp * 2.f / (float)M,
-                     G, (u16*)v_bf16);
+  if (G <= 256 * 20)
+    hipLaunchKernelGGL(gp_penalty_regs_kernel<20>, dim3(M), dim3(256), 0, ST, V, ldv, rowpen, UX, ldu,
+                       lambda_gp * 2.f / (float)M, G, (u16*)v_bf16);
+  else
+    hipLaunchKernelGGL(gp_penalty_kernel, dim3(M), dim3(256), 0, ST, V, ldv, rowpen, UX, ldu, lambda_gp * 2.f / (float)M,
+                       G, (u16*)v_bf16);
   return cg_launch_status();
 }
 
