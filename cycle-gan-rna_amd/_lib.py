@@ -64,7 +64,7 @@ SIGNATURES = {
     "cg_to_bf16": ([P, I, P, I, I, I, P], I),
     "cg_embed_gather": ([P, I, P, I, P, I, I, I, P, P], I),
     "cg_copy_bf16": ([P, P, I, P, I, I, I, P], I),
-    "cg_label_colsum": ([P, P, I, P, I, I, I, I, F, I, P], I),
+    "cg_label_colsum": ([P, P, I, P, I, I, I, I, F, I, P, I, P], I),
     "cg_embed_scatter": ([P, I, P, I, P, I, I, I, I, P], I),
     "cg_reparam_fwd": ([P, I, P, I, P, I, I, P], I),
     "cg_reparam_bwd": ([P, I, P, I, P, I, P, P, I, F, I, I, P], I),

@@ -559,7 +559,8 @@ __global__ void __launch_bounds__(64) sum_parts_kernel(double* totals, const flo
 }  // namespace
 
 // Sums of the rows of X by label: out[t][n] (+)= scale * sum over rows m with labels[m] == t of X[m][n]; rows whose
-// label lies outside [0, n_types) belong to no cell and are skipped.  A workgroup owns 16 columns over all rows with
+// label lies outside [0, n_types) belong to no cell and are skipped; with `minus`, a second label per row, the row is also
+// subtracted at that label.  A workgroup owns 16 columns over all rows with
 // RL = blockDim.x / 16 row lanes: a thread walks every RL-th row and adds into the LDS accumulator of its own
 // (row lane, column) for the row's label (eight loads in flight, unconditional: row clamped, contribution zeroed),
 // then the row lanes are added in order - deterministic.  A wave's 4 row lanes x 16 columns fall on 64 distinct
@@ -568,7 +569,7 @@ __global__ void __launch_bounds__(64) sum_parts_kernel(double* totals, const flo
 constexpr int LC_MAX_TYPES = 32;
 __global__ void __launch_bounds__(1024) label_colsum_kernel(float* out, const float* X, int ldx, const int64_t* labels,
                                                             int lstride, int M, int N, int n_types, float scale,
-                                                            int accumulate) {
+                                                            int accumulate, const int64_t* minus, int mstride) {
   extern __shared__ float lc_acc[];     // [n_types][RL][16]
   const int RL = blockDim.x >> 4, c = threadIdx.x & 15, rl = threadIdx.x >> 4, col = blockIdx.x * 16 + c,
             colc = min(col, N - 1);
@@ -577,16 +578,20 @@ __global__ void __launch_bounds__(1024) label_colsum_kernel(float* out, const fl
   float* mine = lc_acc + rl * 16 + c;
   for (int m0 = rl; m0 < M; m0 += RL * 8) {
     float v[8];
-    long long lab[8];
+    long long lab[8], labm[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int m = min(m0 + RL * u, M - 1);
       v[u] = X[(size_t)m * ldx + colc];
       lab[u] = labels[(size_t)m * lstride];
+      labm[u] = minus ? minus[(size_t)m * mstride] : -1;
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (m0 + RL * u < M && lab[u] >= 0 && lab[u] < n_types) mine[(int)lab[u] * RL * 16] += v[u];
+    for (int u = 0; u < 8; ++u) {
+      if (m0 + RL * u >= M) continue;
+      if (lab[u] >= 0 && lab[u] < n_types) mine[(int)lab[u] * RL * 16] += v[u];
+      if (labm[u] >= 0 && labm[u] < n_types) mine[(int)labm[u] * RL * 16] -= v[u];
+    }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < n_types * 16; i += blockDim.x) {
@@ -662,12 +667,14 @@ extern "C" int cg_embed_scatter(float* dtable, int E, const float* dout, int ldd
 }
 
 extern "C" int cg_label_colsum(float* out, const float* X, int ldx, const int64_t* labels, int lstride, int M, int N,
-                               int n_types, float scale, int accumulate, void* stream) {
+                               int n_types, float scale, int accumulate, const int64_t* minus_labels, int mstride,
+                               void* stream) {
   if (!out || !X || !labels || M < 0 || N <= 0 || ldx < N || lstride < 1 || n_types <= 0) return CG_ERR_BAD_ARG;
+  if (minus_labels && mstride < 1) return CG_ERR_BAD_ARG;
   if (n_types > LC_MAX_TYPES) return CG_ERR_UNSUPPORTED;
   const int RL = n_types <= 16 ? 64 : 32;
   hipLaunchKernelGGL(label_colsum_kernel, dim3((N + 15) / 16), dim3(RL * 16), (size_t)n_types * RL * 64, ST, out, X, ldx,
-                     labels, lstride, M, N, n_types, scale, accumulate);
+                     labels, lstride, M, N, n_types, scale, accumulate, minus_labels, mstride);
   return cg_launch_status();
 }
 

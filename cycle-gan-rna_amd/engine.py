@@ -906,8 +906,7 @@ class CriticStack:
             off = Gd
             for i, (k, w) in enumerate(tables):
                 T = self._label_sums(k)
-                ops.label_colsum(T, av, self.lab[b:2 * b, i:i + 1])
-                ops.label_colsum(T, av, self.lab[:b, i:i + 1], scale=-1.0, accumulate=True)
+                ops.label_colsum(T, av, self.lab[b:2 * b, i:i + 1], minus=self.lab[:b, i:i + 1])
                 ops.gemm(G["model.0.weight"][:, off:off + w], T, P[k], True, False, accumulate=True)
                 off += w
         elif labels:

@@ -488,13 +488,16 @@ class HipOps:
 
     LABEL_COLSUM_MAX_TYPES = 32
 
-    def label_colsum(self, out, X, labels, scale=1.0, accumulate=False):
-        """out[t] (+)= scale * sum of the rows of X whose label is t (labels (M, 1) or (M,) int64; others skipped)."""
+    def label_colsum(self, out, X, labels, scale=1.0, accumulate=False, minus=None):
+        """out[t] (+)= scale * sum of the rows of X whose label is t (labels (M, 1) or (M,) int64; others skipped);
+        minus: a second label per row at which the row is subtracted."""
         n_types, N = out.shape
         M = X.shape[0]
         assert X.shape[1] == N and labels.shape[0] == M and out.is_contiguous() and labels.dtype == torch.int64
+        assert minus is None or (minus.shape[0] == M and minus.dtype == torch.int64)
         st = self.lib.cg_label_colsum(_ptr(out), _ptr(X), _ld(X), _ptr(labels), labels.stride(0), M, N, n_types,
-                                      float(scale), int(accumulate), self._stream())
+                                      float(scale), int(accumulate), _ptr(minus), minus.stride(0) if minus is not None else 0,
+                                      self._stream())
         _lib.check(st, "cg_label_colsum")
 
     def reparam_fwd(self, z, ml, eps):

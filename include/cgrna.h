@@ -279,10 +279,11 @@ int cg_embed_gather(float* out, int ldo, const float* table, int E, const int64_
  * n_types <= 32.  The gradient of an embedding table that enters a Linear layer beside the data
  * (GAN_functions.py:161-165,181-184) is  sum over rows with label t of (dh W_e)[m]  =  (sum over those rows of
  * dh[m]) W_e:  summing the hidden gradients by label first turns a rows x E x hidden product and a scatter into
- * this pass and an n_types x E x hidden product.
+ * this pass and an n_types x E x hidden product.  minus_labels (may be NULL): a second label per row at which the row
+ * is subtracted in the same pass (the difference of two such sums over one X).
  */
 int cg_label_colsum(float* out, const float* X, int ldx, const int64_t* labels, int lstride, int M, int N,
-                    int n_types, float scale, int accumulate, void* stream);
+                    int n_types, float scale, int accumulate, const int64_t* minus_labels, int mstride, void* stream);
 /* Its gradient: dtable[t, e] (+)= sum over rows with label t of dout[m, e] (deterministic order). */
 int cg_embed_scatter(float* dtable, int E, const float* dout, int lddo, const int64_t* labels, int lstride,
                      int M, int n_types, int accumulate, void* stream);

@@ -257,12 +257,17 @@ class CpuOps:
 
     LABEL_COLSUM_MAX_TYPES = 32
 
-    def label_colsum(self, out, X, labels, scale=1.0, accumulate=False):
-        """cg_label_colsum: out[t] (+)= scale * sum of the rows of X with label t; other labels are skipped."""
+    def label_colsum(self, out, X, labels, scale=1.0, accumulate=False, minus=None):
+        """cg_label_colsum: out[t] (+)= scale * sum of the rows of X with label t; other labels are skipped; minus: a
+        second label per row at which the row is subtracted."""
         lab = labels.reshape(labels.shape[0], -1)[:, 0]
         keep = (lab >= 0) & (lab < out.shape[0])
         acc = torch.zeros_like(out)
         acc.index_add_(0, lab[keep], X.contiguous()[keep])
+        if minus is not None:
+            lab = minus.reshape(minus.shape[0], -1)[:, 0]
+            keep = (lab >= 0) & (lab < out.shape[0])
+            acc.index_add_(0, lab[keep], -X.contiguous()[keep])
         out.copy_((out if accumulate else 0) + scale * acc)
 
     def reparam_fwd(self, z, ml, eps):

@@ -889,6 +889,11 @@ def test_label_colsum(ops, M, N, T):
     exp2 = torch.zeros(T, N)
     cpu.label_colsum(exp2, x, lab)
     close(plain, exp2, 1e-5)
+    lab2 = torch.randint(-1, T, (M, 1), generator=torch.Generator().manual_seed(5))     # a second label: subtracted there
+    diff, exp3 = torch.full((T, N), 7.0).cuda(), torch.zeros(T, N)
+    ops.label_colsum(diff, xd, ld, minus=lab2.cuda())
+    cpu.label_colsum(exp3, x, lab, minus=lab2)
+    close(diff, exp3, 1e-5)
 
 
 @pytest.mark.parametrize("M,N,K,ta,tb,epi,acc,dtype", [
