@@ -80,6 +80,8 @@ SIGNATURES = {
     "cg_reduce_centroid_sq": ([P, P, P, I, P, I, P, I, I, I, I, P], I),
     "cg_reduce_kl": ([P, P, P, I, I, I, P], I),
     "cg_colsum": ([P, P, I, I, I, F, I, P], I),
+    "cg_colsum3": ([P, P, I, I, I, F, I, P, P, I, I, I, F, I, P, P, I, I, I, F, I, P], I),
+    "cg_reduce_sum_seg": ([P, P, P, I, I, I, I, P], I),
     "cg_reduce_sqdiff": ([P, P, P, I, P, I, I, I, P], I),
     "cg_colvar_mean": ([P, P, P, I, I, I, P], I),
     "cg_l1_bwd": ([P, I, P, I, P, I, P, I, F, I, I, I, P], I),

@@ -61,8 +61,9 @@ __global__ void embed_gather_kernel(float* out, int ldo, const float* table, int
   if (i >= M * E) return;
   const int m = i / E, e = i % E;
   int64_t t = labels[(size_t)m * lstride];
+  const bool none = t < 0;      // a negative label marks a row that belongs to no cell: zeros
   t = t < 0 ? 0 : (t >= n_types ? n_types - 1 : t);
-  const float v = table[t * E + e];
+  const float v = none ? 0.f : table[t * E + e];
   out[(size_t)m * ldo + e] = v;
   if (out16) out16[(size_t)m * ldo + e] = f2bf(v);
 }
@@ -337,6 +338,16 @@ __global__ void __launch_bounds__(256) reduce_sum_kernel(float* parts, int* npar
   write_part(s, parts, nparts);
 }
 
+// nseg equal row segments of X, segment k into slot k of consecutive reductions (parts + k * CG_MAX_PARTS, nparts + k):
+// the partial sums of nseg calls of reduce_sum_kernel in one launch.
+__global__ void __launch_bounds__(256) reduce_sum_seg_kernel(float* parts, int* nparts, const float* X, int ldx,
+                                                             int seg_rows, int N) {
+  const float* Xs = X + (size_t)blockIdx.z * seg_rows * ldx;
+  float s = 0.f;
+  CG_2D_LOOP(seg_rows, N) s += Xs[(size_t)m * ldx + col];
+  write_part(s, parts + (size_t)blockIdx.z * CG_MAX_PARTS, nparts + blockIdx.z);
+}
+
 __global__ void __launch_bounds__(256) reduce_l1_kernel(float* parts, int* nparts, const float* A, int lda,
                                                         const float* B, int ldb, int M, int N) {
   float s = 0.f;
@@ -406,6 +417,33 @@ __global__ void __launch_bounds__(1024) colsum_kernel(float* out, const float* X
     double a = 0.0;
     for (int r = 0; r < 32; ++r) a += lds[r * 32 + c];
     out[col] = (accumulate ? out[col] : 0.f) + (float)(a * (double)scale);
+  }
+}
+
+// Up to three column sums in one launch (the bias gradients at the end of a backward chain): the strips of the jobs
+// one after the other, each summed exactly as colsum_kernel does.
+struct ColsumJob {
+  float* out; const float* X; int ldx, M, N; float scale; int accumulate;
+};
+struct ColsumJobs {
+  ColsumJob j[3];
+  int first[4];     // first strip of each job; first[3] = number of strips
+};
+__global__ void __launch_bounds__(1024) colsum_multi_kernel(ColsumJobs js) {
+  __shared__ double lds[32 * 32];
+  const int k = (int)blockIdx.x >= js.first[2] ? 2 : ((int)blockIdx.x >= js.first[1] ? 1 : 0);
+  const ColsumJob& jb = js.j[k];
+  const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;
+  const int col = ((int)blockIdx.x - js.first[k]) * 32 + c;
+  double s = 0.0;
+  if (col < jb.N)
+    for (int m = r0; m < jb.M; m += 32) s += jb.X[(size_t)m * jb.ldx + col];
+  lds[r0 * 32 + c] = s;
+  __syncthreads();
+  if (r0 == 0 && col < jb.N) {
+    double a = 0.0;
+    for (int r = 0; r < 32; ++r) a += lds[r * 32 + c];
+    jb.out[col] = (jb.accumulate ? jb.out[col] : 0.f) + (float)(a * (double)jb.scale);
   }
 }
 
@@ -812,6 +850,41 @@ extern "C" int cg_colsum(float* out, const float* X, int ldx, int M, int N, floa
                          void* stream) {
   if (!out || !X || M <= 0 || N <= 0 || ldx < N) return CG_ERR_BAD_ARG;
   hipLaunchKernelGGL(colsum_kernel, dim3((N + 31) / 32), dim3(1024), 0, ST, out, X, ldx, M, N, scale, accumulate);
+  return cg_launch_status();
+}
+
+extern "C" int cg_colsum3(float* out0, const float* X0, int ldx0, int M0, int N0, float scale0, int accumulate0,
+                          float* out1, const float* X1, int ldx1, int M1, int N1, float scale1, int accumulate1,
+                          float* out2, const float* X2, int ldx2, int M2, int N2, float scale2, int accumulate2,
+                          void* stream) {
+  ColsumJobs js{};
+  float* outs[3] = {out0, out1, out2};
+  const float* Xs[3] = {X0, X1, X2};
+  const int ld[3] = {ldx0, ldx1, ldx2}, Ms[3] = {M0, M1, M2}, Ns[3] = {N0, N1, N2}, ac[3] = {accumulate0, accumulate1, accumulate2};
+  const float sc[3] = {scale0, scale1, scale2};
+  int strips = 0;
+  for (int k = 0; k < 3; ++k) {
+    js.first[k] = strips;
+    if (!outs[k]) {       // an unused job: no strips
+      js.j[k] = ColsumJob{nullptr, nullptr, 0, 0, 0, 0.f, 0};
+      continue;
+    }
+    if (!Xs[k] || Ms[k] <= 0 || Ns[k] <= 0 || ld[k] < Ns[k]) return CG_ERR_BAD_ARG;
+    js.j[k] = ColsumJob{outs[k], Xs[k], ld[k], Ms[k], Ns[k], sc[k], ac[k]};
+    strips += (Ns[k] + 31) / 32;
+  }
+  js.first[3] = strips;
+  if (strips == 0) return CG_OK;
+  hipLaunchKernelGGL(colsum_multi_kernel, dim3(strips), dim3(1024), 0, ST, js);
+  return cg_launch_status();
+}
+
+extern "C" int cg_reduce_sum_seg(float* parts, int* nparts, const float* X, int ldx, int seg_rows, int nseg, int N,
+                                 void* stream) {
+  if (!parts || !nparts || !X || seg_rows <= 0 || nseg <= 0 || N <= 0 || ldx < N) return CG_ERR_BAD_ARG;
+  Grid2 g = grid_red(seg_rows, N);
+  hipLaunchKernelGGL(reduce_sum_seg_kernel, dim3(g.grid.x, g.grid.y, nseg), g.block, 0, ST, parts, nparts, X, ldx,
+                     seg_rows, N);
   return cg_launch_status();
 }
 

@@ -775,6 +775,7 @@ class CriticStack:
         self.rowpen = Z(B)
         self.ubar, self.mbar = Z(1024), Z(1024)
         self.b, self.have_labels = 0, True
+        self._late_colsums = []
 
     def x_seg(self, i, b):
         return self.x[i * b:(i + 1) * b]
@@ -804,7 +805,11 @@ class CriticStack:
         if interp is not None:
             self.alpha = interp
         # row blocks of the stacked input that hold input batches: 0, 1 and - in the critic step's layout - 3
+        # (with labels, the critic step's layout takes all four blocks in one launch: the rows of block 2 carry the
+        # label -1, no cell, and get the zeros that V needs under the embedding columns)
         blocks = [(0, 2 * b), (3 * b, 4 * b)] if self.gp_layout else [(0, Rx)]
+        if self.gp_layout and self.have_labels:
+            blocks = [(0, 4 * b)]
         for lo, hi in blocks:
             if self.have_labels:
                 _embed_gather(ops, self.emb[lo:hi], P, self.lab[lo:hi])
@@ -850,14 +855,23 @@ class CriticStack:
         W1 = P["model.0.weight"]
         dval, dh3 = self._dval_const[key], self.g256[:R]
         ops.gemm(G["model.9.weight"], dval, self.a3[:R], True, False, accumulate=True)
-        ops.colsum(G["model.9.bias"], dval, 1.0, True)
+        # the head's bias gradient is the sum of the seed gradients: exactly zero for the critic step's (-1/b, 1/b)
+        # (the two halves cancel term by term), and adding zero is left out
+        if sum(scales) != 0.0:
+            ops.colsum(G["model.9.bias"], dval, 1.0, True)
         ops.gemm(dh3, dval, P["model.9.weight"], False, False, epi=EPI_MUL, E=self.pm3[:R])
         ops.gemm(G["model.7.weight"], dh3, self.a2[:R], True, False, accumulate=True)
-        ops.colsum(G["model.7.bias"], dh3, 1.0, True)
         dh2 = self.g512[:R]
         ops.gemm(dh2, dh3, P["model.7.weight"], False, False, epi=EPI_MUL, E=self.pm2[:R])
         ops.gemm(G["model.4.weight"], dh2, self.a1[:R], True, False, accumulate=True)
-        ops.colsum(G["model.4.bias"], dh2, 1.0, True)
+        # the bias gradients of this chain and the column sum the penalty chain left for here, in one launch
+        jobs = [(G["model.7.bias"], dh3, 1.0, True), (G["model.4.bias"], dh2, 1.0, True)] + self._late_colsums
+        self._late_colsums = []
+        if hasattr(ops, "colsum_multi"):
+            ops.colsum_multi(jobs)
+        else:
+            for out, X, scale, acc in jobs:
+                ops.colsum(out, X, scale, acc)
         da1 = self.g1024a[:R]
         ops.gemm(da1, dh2, P["model.4.weight"], False, False)
         dh0 = self.g1024b[:R]
@@ -957,7 +971,7 @@ class CriticStack:
         u3, u2, u1 = self.g256[sl], self.g512[sl], self.g1024a[sl]
         u0, vh0 = self.g1024b[2 * b:3 * b], self.g1024b[3 * b:4 * b]
         ux = self.xe[2 * b:3 * b, :Gd]
-        if self.E:      # V is zero under the embedding columns; a batch of another size leaves other rows' values there
+        if self.E and not self.have_labels:      # V is zero under the embedding columns (with labels: forward() did it)
             if hasattr(ops, "copy"):
                 ops.copy(self.xe[2 * b:3 * b, Gd:self.W], self.zero_emb[:b])
             else:
@@ -981,7 +995,9 @@ class CriticStack:
         ops.gemm(G["model.7.weight"], u3, t2, True, False, accumulate=True)
         vu3 = self.h256[:b]
         ops.gemm(vu3, t2, W3, False, True, epi=EPI_MUL, E=pm3)
-        ops.colsum(G["model.9.weight"], vu3, 1.0, True)
+        # d(penalty)/d(head weight) = column sums of vu3: a leaf, summed together with the bias gradients at the end of
+        # backward_params(), which the critic step calls next (h256 is not written in between)
+        self._late_colsums = [(G["model.9.weight"], vu3, 1.0, True)]
 
 
 class PendingMetrics:
@@ -1477,8 +1493,11 @@ class StepEngine(EngineBase):
                               fake_lab.contiguous() if ds.have_labels else None, interp_block=3)
             ds.alpha = alpha
             val, _ = ds.forward(b, m1, m2, (0, 1, 2), interp=alpha if self.interp_by_linearity else None)
-            ops.reduce_sum(self.red, s0, val[:b])
-            ops.reduce_sum(self.red, s0 + 1, val[b:2 * b])
+            if hasattr(ops, "reduce_sum_seg"):
+                ops.reduce_sum_seg(self.red, s0, val[:2 * b], 2)
+            else:
+                ops.reduce_sum(self.red, s0, val[:b])
+                ops.reduce_sum(self.red, s0 + 1, val[b:2 * b])
         # One branch per critic, forward and backward (nothing of one critic waits for the other): its gradients cleared, the penalty's double-backward chain on the
         # interpolates, the Wasserstein chain on the real and the generated rows, then the first layer's weight
         # gradient from what both left behind (CriticStack.w1_grad).  Every tensor is accumulated by one stream, so

@@ -626,6 +626,27 @@ class HipOps:
         st = self.lib.cg_colsum(_ptr(out), _ptr(X), _ld(X), M, N, float(scale), int(accumulate), self._stream())
         _lib.check(st, "cg_colsum")
 
+    def colsum_multi(self, jobs):
+        """[(out, X, scale, accumulate), ...]: colsum of every job, three per launch."""
+        for i in range(0, len(jobs), 3):
+            args = []
+            for k in range(3):
+                if i + k < len(jobs):
+                    out, X, scale, acc = jobs[i + k]
+                    M, N = X.shape
+                    assert out.numel() == N
+                    args += [_ptr(out), _ptr(X), _ld(X), M, N, float(scale), int(acc)]
+                else:
+                    args += [0, 0, 0, 0, 0, 0.0, 0]
+            _lib.check(self.lib.cg_colsum3(*args, self._stream()), "cg_colsum3")
+
+    def reduce_sum_seg(self, red, slot, X, nseg):
+        """reduce_sum of the nseg equal row segments of X into the slots slot .. slot + nseg - 1."""
+        assert X.dim() == 2 and X.shape[0] % nseg == 0
+        p, n = self._slot(red, slot)
+        st = self.lib.cg_reduce_sum_seg(p, n, _ptr(X), _ld(X), X.shape[0] // nseg, nseg, X.shape[1], self._stream())
+        _lib.check(st, "cg_reduce_sum_seg")
+
     def colvar_mean(self, out, ws, X):
         M, N = X.shape
         assert ws.dtype == torch.float64 and ws.numel() >= (N + 31) // 32

@@ -269,7 +269,8 @@ int cg_to_bf16(void* out, int ldo, const float* x, int ldx, int M, int N, void* 
  * whose image the bf16 products read (the critic's input rows in the generator step, GAN_functions.py:347,366-371). */
 int cg_copy_bf16(float* out, void* out_bf16, int ldo, const float* x, int ldx, int M, int N, void* stream);
 
-/* Embedding lookup (GAN_functions.py:135,181): out[m, 0:E] = table[labels[m*lstride], 0:E].
+/* Embedding lookup (GAN_functions.py:135,181): out[m, 0:E] = table[labels[m*lstride], 0:E]; a negative label (a row
+ * that belongs to no cell) gives zeros.
  * out_bf16 (may be NULL): bf16 image of `out`, same leading dimension. */
 int cg_embed_gather(float* out, int ldo, const float* table, int E, const int64_t* labels, int lstride,
                     int M, int n_types, void* out_bf16, void* stream);
@@ -370,6 +371,10 @@ int cg_gp_penalty(float* V, int ldv, float* rowpen, const float* UX, int ldu, fl
  */
 /* sum of all elements of X (critic means :330,:335,:347; row-penalty mean :203). */
 int cg_reduce_sum(float* parts, int* nparts, const float* X, int ldx, int M, int N, void* stream);
+/* nseg cg_reduce_sum in one launch: row segment k (seg_rows rows) of X into reduction k of nseg consecutive ones
+ * (parts + k * CG_MAX_PARTS, nparts + k): the critic's means over the real and the generated batch (:330,:335) when
+ * both were evaluated as one stacked batch.  The same partial sums as nseg calls. */
+int cg_reduce_sum_seg(float* parts, int* nparts, const float* X, int ldx, int seg_rows, int nseg, int N, void* stream);
 /* sum |A - B| (L1 cycle loss :353-357). */
 int cg_reduce_l1(float* parts, int* nparts, const float* A, int lda, const float* B, int ldb, int M, int N, void* stream);
 /* sum pred - target*log(pred + 1e-10): poisson_loss (GAN_functions.py:216-217) before its mean; the cycle term of
@@ -384,6 +389,11 @@ int cg_reduce_kl(float* parts, int* nparts, const float* ml, int ldml, int M, in
 /* out[n] (+)= scale * sum_m X[m,n]: column means (feature matching :368,:372; scale = 1/M) and the
  * bias gradients of nn.Linear (scale = 1). */
 int cg_colsum(float* out, const float* X, int ldx, int M, int N, float scale, int accumulate, void* stream);
+/* Up to three cg_colsum in one launch (the bias gradients of consecutive nn.Linear layers at the end of a backward
+ * chain, GAN_functions.py:165-174); a job whose out is NULL is skipped.  The same bits as three calls. */
+int cg_colsum3(float* out0, const float* X0, int ldx0, int M0, int N0, float scale0, int accumulate0,
+               float* out1, const float* X1, int ldx1, int M1, int N1, float scale1, int accumulate1,
+               float* out2, const float* X2, int ldx2, int M2, int N2, float scale2, int accumulate2, void* stream);
 /* sum (A - B)^2 (feature-matching MSE between two mean vectors :368,:372). */
 int cg_reduce_sqdiff(float* parts, int* nparts, const float* A, int lda, const float* B, int ldb, int M, int N,
                      void* stream);

@@ -246,7 +246,9 @@ class CpuOps:
         out.fill_(float(coef[idx]) * scale)
 
     def embed_gather(self, out, table, labels):
-        out.copy_(table[labels.reshape(labels.shape[0], -1)[:, 0]])
+        lab = labels.reshape(labels.shape[0], -1)[:, 0]
+        rows = table[lab.clamp(min=0)]
+        out.copy_(torch.where((lab < 0)[:, None], torch.zeros_like(rows), rows))    # no cell: zeros
 
     def embed_scatter(self, dtable, dout, labels, accumulate):
         lab = labels.reshape(labels.shape[0], -1)[:, 0]

@@ -1082,3 +1082,35 @@ def test_attention_block_backward_in_one_launch(ops, n_cells):
     assert float(((a["tot"] - b_["tot"]).abs() / b_["tot"].abs().clamp_min(1e-30)).max()) < 1e-10
     for k in ("G1", "wp2", "dg2", "db2", "s4"):
         close(a[k], b_[k].cpu(), 2e-6, f"consumer of the fused sums: {k}")
+
+
+def test_merged_leaf_launches(ops):
+    """cg_colsum3 and cg_reduce_sum_seg give the bits of the separate calls they stand for; cg_embed_gather writes
+    zeros for a negative label."""
+    X = [dev(rnd(1024, 512, seed=1)), dev(rnd(1024, 1024, seed=2)), dev(rnd(512, 256, seed=3)), dev(rnd(37, 50, seed=4))]
+    base = [dev(rnd(x.shape[1], seed=9)) for x in X]
+    sep, mul = [b_.clone() for b_ in base], [b_.clone() for b_ in base]
+    for o, x, k in zip(sep, X, range(4)):
+        ops.colsum(o, x, 1.0 + k, k != 2)
+    ops.colsum_multi([(o, x, 1.0 + k, k != 2) for o, x, k in zip(mul, X, range(4))])
+    for a, b_ in zip(mul, sep):
+        assert torch.equal(a, b_)
+    from cycle_gan_rna_amd.ops import MAX_PARTS
+    val = dev(rnd(3 * 512, 1, seed=5))
+    reds = []
+    for form in range(2):
+        red = (torch.zeros(4 * MAX_PARTS).cuda(), torch.zeros(4, dtype=torch.int32).cuda())
+        if form == 0:
+            for k in range(3):
+                ops.reduce_sum(red, 1 + k, val[k * 512:(k + 1) * 512])
+        else:
+            ops.reduce_sum_seg(red, 1, val, 3)
+        reds.append(red)
+    assert torch.equal(reds[0][0], reds[1][0]) and torch.equal(reds[0][1], reds[1][1]) and int(reds[0][1][1]) > 0
+    table = dev(rnd(12, 12, seed=6))
+    lab = torch.tensor([[3], [-1], [11], [0], [-1]]).cuda()
+    out = torch.full((5, 12), 7.0).cuda()
+    ops.embed_gather(out, table, lab)
+    exp = torch.empty(5, 12)
+    cpu.embed_gather(exp, table.cpu(), lab.cpu())
+    assert torch.equal(out.cpu(), exp) and float(out[1].abs().max()) == 0.0 and float(out[4].abs().max()) == 0.0
