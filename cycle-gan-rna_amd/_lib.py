@@ -74,6 +74,7 @@ SIGNATURES = {
     "cg_critic_inputs": ([P, I, P, I, P, I, P, I, I, P, P, P, I, I, P, P], I),
     "cg_gp_combine": ([P, I, P, I, P, P, I, P, I, I, P, I, I, I, P, P], I),
     "cg_gp_penalty": ([P, I, P, P, I, F, I, I, P, P], I),
+    "cg_gp_penalty_parts": ([P, I, P, P, P, I, F, I, I, P, P], I),
     "cg_reduce_sum": ([P, P, P, I, I, I, P], I),
     "cg_reduce_l1": ([P, P, P, I, P, I, I, I, P], I),
     "cg_reduce_poisson": ([P, P, P, I, P, I, I, I, P], I),

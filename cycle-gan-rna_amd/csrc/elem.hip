@@ -268,10 +268,12 @@ __global__ void gp_combine_kernel(float* D, int ldd, const float* VH, int ldv, c
       dE[(size_t)m * ldde + threadIdx.x] = emb[(size_t)(M + m) * lde + threadIdx.x] - emb[(size_t)m * lde + threadIdx.x];
 }
 
+// nparts (may be nullptr): rowpen is the partial-sum array of a reduction (see cg_reduce_*), whose count is set here.
 __global__ void __launch_bounds__(256) gp_penalty_kernel(float* V, int ldv, float* rowpen, const float* UX, int ldu,
-                                                         float lam2_over_m, int G, u16* V16) {
+                                                         float lam2_over_m, int G, u16* V16, int* nparts) {
   __shared__ float lds[17];
   const int m = blockIdx.x;
+  if (nparts && m == 0 && threadIdx.x == 0) *nparts = gridDim.x;
   float s = 0.f;
   for (int c = threadIdx.x; c < G; c += 256) {
     const float u = UX[(size_t)m * ldu + c];
@@ -293,9 +295,10 @@ __global__ void __launch_bounds__(256) gp_penalty_kernel(float* V, int ldv, floa
 // read of UX instead of two; the squares are added in the same order).
 template <int NV>
 __global__ void __launch_bounds__(256) gp_penalty_regs_kernel(float* V, int ldv, float* rowpen, const float* UX, int ldu,
-                                                              float lam2_over_m, int G, u16* V16) {
+                                                              float lam2_over_m, int G, u16* V16, int* nparts) {
   __shared__ float lds[17];
   const int m = blockIdx.x;
+  if (nparts && m == 0 && threadIdx.x == 0) *nparts = gridDim.x;
   float u[NV];
   float s = 0.f;
 #pragma unroll
@@ -794,16 +797,27 @@ extern "C" int cg_gp_combine(float* D, int ldd, const float* VH, int ldv, const 
   return cg_launch_status();
 }
 
-extern "C" int cg_gp_penalty(float* V, int ldv, float* rowpen, const float* UX, int ldu, float lambda_gp, int M, int G,
-                             void* v_bf16, void* stream) {
+static int launch_gp_penalty(float* V, int ldv, float* rowpen, int* nparts, const float* UX, int ldu, float lambda_gp,
+                             int M, int G, void* v_bf16, void* stream) {
   if (!V || !rowpen || !UX || M <= 0 || G <= 0 || ldv < G || ldu < G) return CG_ERR_BAD_ARG;
   if (G <= 256 * 20)
     hipLaunchKernelGGL(gp_penalty_regs_kernel<20>, dim3(M), dim3(256), 0, ST, V, ldv, rowpen, UX, ldu,
-                       lambda_gp * 2.f / (float)M, G, (u16*)v_bf16);
+                       lambda_gp * 2.f / (float)M, G, (u16*)v_bf16, nparts);
   else
     hipLaunchKernelGGL(gp_penalty_kernel, dim3(M), dim3(256), 0, ST, V, ldv, rowpen, UX, ldu, lambda_gp * 2.f / (float)M,
-                       G, (u16*)v_bf16);
+                       G, (u16*)v_bf16, nparts);
   return cg_launch_status();
+}
+
+extern "C" int cg_gp_penalty(float* V, int ldv, float* rowpen, const float* UX, int ldu, float lambda_gp, int M, int G,
+                             void* v_bf16, void* stream) {
+  return launch_gp_penalty(V, ldv, rowpen, nullptr, UX, ldu, lambda_gp, M, G, v_bf16, stream);
+}
+
+extern "C" int cg_gp_penalty_parts(float* V, int ldv, float* parts, int* nparts, const float* UX, int ldu,
+                                   float lambda_gp, int M, int G, void* v_bf16, void* stream) {
+  if (!nparts || M > CG_MAX_PARTS) return CG_ERR_BAD_ARG;
+  return launch_gp_penalty(V, ldv, parts, nparts, UX, ldu, lambda_gp, M, G, v_bf16, stream);
 }
 
 extern "C" int cg_reduce_sum(float* parts, int* nparts, const float* X, int ldx, int M, int N, void* stream) {

@@ -838,6 +838,25 @@ class CriticStack:
         ops.gemm(self.val[:R], self.a3[:R], P["model.9.weight"], False, True, bias=P["model.9.bias"])
         return self.val[:R], self.a3[:R]
 
+    _stages_done = False
+    merged_stages = not os.environ.get("CGRNA_NO_MERGED_STAGES")
+
+    def first_order_stages(self, b, scales):
+        """The first two backward stages (head, third layer) of the critic step's two first-order chains - the penalty's
+        on the interpolates (seed 1) and the Wasserstein terms' on the real and the generated rows (seeds `scales`) -
+        as one chain over all three row blocks: the same weights, adjacent rows of the same workspaces, two launches
+        instead of four.  gp_backward() and backward_params() of the same step then start from g256 / g512."""
+        ops, P = self.ops, self.net.P
+        assert self.gp_layout and len(scales) == 2
+        key = (b, tuple(scales), "all")
+        if key not in self._dval_const:
+            seed = torch.tensor(list(scales) + [1.0], dtype=torch.float32).repeat_interleave(b)[:, None]
+            self._dval_const[key] = ops.to_device(seed)
+        R = 3 * b
+        ops.gemm(self.g256[:R], self._dval_const[key], P["model.9.weight"], False, False, epi=EPI_MUL, E=self.pm3[:R])
+        ops.gemm(self.g512[:R], self.g256[:R], P["model.7.weight"], False, False, epi=EPI_MUL, E=self.pm2[:R])
+        self._stages_done = True
+
     def backward_params(self, b, scales):
         """Critic step: parameter gradients of  sum_s scales[s] * sum(validity of segment s)  over the first
         len(scales) segments (needs nx == nseg), accumulated into the gradient arena - except the first layer's
@@ -859,10 +878,13 @@ class CriticStack:
         # (the two halves cancel term by term), and adding zero is left out
         if sum(scales) != 0.0:
             ops.colsum(G["model.9.bias"], dval, 1.0, True)
-        ops.gemm(dh3, dval, P["model.9.weight"], False, False, epi=EPI_MUL, E=self.pm3[:R])
+        if not self._stages_done:
+            ops.gemm(dh3, dval, P["model.9.weight"], False, False, epi=EPI_MUL, E=self.pm3[:R])
         ops.gemm(G["model.7.weight"], dh3, self.a2[:R], True, False, accumulate=True)
         dh2 = self.g512[:R]
-        ops.gemm(dh2, dh3, P["model.7.weight"], False, False, epi=EPI_MUL, E=self.pm2[:R])
+        if not self._stages_done:
+            ops.gemm(dh2, dh3, P["model.7.weight"], False, False, epi=EPI_MUL, E=self.pm2[:R])
+        self._stages_done = False
         ops.gemm(G["model.4.weight"], dh2, self.a1[:R], True, False, accumulate=True)
         # the bias gradients of this chain and the column sum the penalty chain left for here, in one launch
         jobs = [(G["model.7.bias"], dh3, 1.0, True), (G["model.4.bias"], dh2, 1.0, True)] + self._late_colsums
@@ -976,14 +998,18 @@ class CriticStack:
                 ops.copy(self.xe[2 * b:3 * b, Gd:self.W], self.zero_emb[:b])
             else:
                 self.xe[2 * b:3 * b, Gd:self.W].zero_()
-        ops.gemm(u3, self.ones[:b], w4, False, False, epi=EPI_MUL, E=pm3)
-        ops.gemm(u2, u3, W3, False, False, epi=EPI_MUL, E=pm2)
+        if not self._stages_done:
+            ops.gemm(u3, self.ones[:b], w4, False, False, epi=EPI_MUL, E=pm3)
+            ops.gemm(u2, u3, W3, False, False, epi=EPI_MUL, E=pm2)
         ops.gemm(u1, u2, W2, False, False, epi=EPI_MUL, E=pm1)
         ops.bn_bwd(u0, u1, h0, None, None, mean, invstd, P["model.1.weight"], None, None, False, 1.0, self.ubar,
                    self.mbar)
         ops.gemm(ux, u0, W1[:, :Gd], False, False)
-        ops.gp_penalty(ux, self.rowpen[:b], ux, lambda_gp)          # ux now holds V
-        ops.reduce_sum(red, slot, self.rowpen[:b])
+        if hasattr(ops, "gp_penalty_parts") and b <= 1024:          # ux then holds V; the row terms are the partial sums
+            ops.gp_penalty_parts(ux, red, slot, ux, lambda_gp)
+        else:
+            ops.gp_penalty(ux, self.rowpen[:b], ux, lambda_gp)
+            ops.reduce_sum(red, slot, self.rowpen[:b])
         w = self.h1024a[:b]
         ops.gemm(w, ux, W1[:, :Gd], False, True)
         t1 = self.h1024b[:b]        # V_u1 times the first layer's activation/dropout factor, in one pass
@@ -1507,6 +1533,8 @@ class StepEngine(EngineBase):
         def backward(name, slot):
             ds = self.dstack[name]
             self.arena_d.net_grad(name).zero_()
+            if ds.merged_stages:
+                ds.first_order_stages(b, (-1.0 / b, 1.0 / b))
             ds.gp_backward(b, 2, cfg["lambda_gp"], self.red, slot)
             ds.backward_params(b, (-1.0 / b, 1.0 / b))
             ds.w1_grad(b)

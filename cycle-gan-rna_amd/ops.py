@@ -582,6 +582,16 @@ class HipOps:
                                     self._twin(V)[0], self._stream())
         _lib.check(st, "cg_gp_penalty")
 
+    def gp_penalty_parts(self, V, red, slot, UX, lambda_gp):
+        """gp_penalty whose row terms go straight into reduction `slot` of `red` (one partial sum per row; at most
+        MAX_PARTS rows): no reduce_sum launch for the penalty's mean."""
+        M, G = UX.shape
+        assert V.shape == UX.shape and M <= MAX_PARTS
+        p, n = self._slot(red, slot)
+        st = self.lib.cg_gp_penalty_parts(_ptr(V), _ld(V), p, n, _ptr(UX), _ld(UX), float(lambda_gp), M, G,
+                                          self._twin(V)[0], self._stream())
+        _lib.check(st, "cg_gp_penalty_parts")
+
     # -- reductions ---------------------------------------------------------------
     # `red` = (parts [n_slots, MAX_PARTS] float32, nparts [n_slots] int32); slot picks the row.
     def _slot(self, red, slot):

@@ -363,6 +363,10 @@ int cg_gp_combine(float* D, int ldd, const float* VH, int ldv, const float* alph
  */
 int cg_gp_penalty(float* V, int ldv, float* rowpen, const float* UX, int ldu, float lambda_gp,
                   int M, int G, void* v_bf16, void* stream);
+/* cg_gp_penalty whose row terms are the partial sums of a reduction (see "reductions" below): parts[m] = (n_m-1)^2
+ * and *nparts = M, M <= CG_MAX_PARTS - the penalty's mean (:203) without a reduction launch of its own. */
+int cg_gp_penalty_parts(float* V, int ldv, float* parts, int* nparts, const float* UX, int ldu, float lambda_gp,
+                        int M, int G, void* v_bf16, void* stream);
 
 /* ---- reductions / losses ---------------------------------------------------
  * Each reduction writes at most CG_MAX_PARTS float partial sums to

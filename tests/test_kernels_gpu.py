@@ -1114,3 +1114,18 @@ def test_merged_leaf_launches(ops):
     exp = torch.empty(5, 12)
     cpu.embed_gather(exp, table.cpu(), lab.cpu())
     assert torch.equal(out.cpu(), exp) and float(out[1].abs().max()) == 0.0 and float(out[4].abs().max()) == 0.0
+
+
+def test_penalty_row_terms_as_partial_sums(ops):
+    """cg_gp_penalty_parts: the row terms land in the reduction slot (one partial per row, the count set), V is the V
+    of cg_gp_penalty."""
+    from cycle_gan_rna_amd.ops import MAX_PARTS
+    M, G = 512, 5000
+    ux = dev(rnd(M, G, seed=9) * 0.05)
+    V0, rp = torch.empty(M, G).cuda(), torch.empty(M).cuda()
+    ops.gp_penalty(V0, rp, ux, 13.0)
+    red = (torch.zeros(3 * MAX_PARTS).cuda(), torch.zeros(3, dtype=torch.int32).cuda())
+    V1 = torch.empty(M, G).cuda()
+    ops.gp_penalty_parts(V1, red, 2, ux, 13.0)
+    assert torch.equal(V0, V1) and torch.equal(red[0][2 * MAX_PARTS:2 * MAX_PARTS + M], rp)
+    assert red[1].tolist() == [0, 0, M] and float(red[0][:2 * MAX_PARTS].abs().max()) == 0.0
