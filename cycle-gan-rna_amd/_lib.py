@@ -24,6 +24,7 @@ P = C.c_void_p
 I = C.c_int
 F = C.c_float
 Z = C.c_size_t
+L = C.c_longlong
 
 
 class GlossDesc(C.Structure):
@@ -94,7 +95,9 @@ SIGNATURES = {
     "cg_adam_amsgrad": ([P, P, P, P, P, Z, P, F, F, F, P, P], I),
     "cg_attn_ln_fwd": ([P, P, P, P, I, I, I, P], I),
     "cg_attn_block_blocks": ([I], I),
-    "cg_attn_block_bwd": ([P, P, P, P, P, P, P, I, I, I, I, P, P, P, P, P], I),
+    "cg_attn_block_bwd": ([P, P, P, P, P, P, P, I, I, I, I, P, P, P, P, I, P], I),
+    "cg_attn_param_reduce_blocks": ([P, L, P, L, I, I, I, P], I),
+    "cg_tok_wgrad_reduce_blocks": ([P, P, L, P, P, L, I, I, P], I),
     "cg_tok_bwd_mid_from": ([P, P, P, P, P, P, P, P, P, P, I, P, P, P, P, P, P, I, P], I),
     "cg_attn_block_fwd": ([P, P, P, P, P, I, P, P, F, P, P, P, P, F, P, P, I, I, I, P, P, P, P, P], I),
     "cg_tok_bn_lin_fwd_from": ([P, P, P, P, P, I, P, P, F, P, P, P, P, F, P, P, I, P], I),

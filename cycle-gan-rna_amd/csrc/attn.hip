@@ -539,8 +539,11 @@ __global__ void __launch_bounds__(256) attn_bwd_kernel(float* __restrict__ dX, f
 
 // 32 parameters per block; 8 lanes per parameter walk the per-block partials, then a fixed-order combine.
 __global__ void __launch_bounds__(256) attn_param_reduce_kernel(float* dparams, const float* wpart, int n_blocks,
-                                                                int accumulate, int np) {
+                                                                int accumulate, int np, long long dstride = 0,
+                                                                long long wstride = 0) {
   __shared__ float lds[8][32];
+  dparams += (size_t)blockIdx.y * dstride;      // blockIdx.y: one of several parameter blocks reduced in one launch
+  wpart += (size_t)blockIdx.y * wstride;
   const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
   const int t = blockIdx.x * 32 + c;
   float s = 0.f;
@@ -921,9 +924,10 @@ extern "C" int cg_attn_ln_fwd(float* Y, const float* X, const float* keep, const
 extern "C" int cg_attn_block_bwd(float* dX, float* dparams, float* wpart, const float* dY, const float* X,
                                  const float* keep, const float* params, int n_cells, int E_, int heads, int accumulate,
                                  const float* T2, const float* mean2, const float* invstd2, double* stat_out,
-                                 void* stream) {
-  if (!dX || !dparams || !wpart || !dY || !X || !params || !T2 || !mean2 || !invstd2 || !stat_out || n_cells <= 0)
+                                 int reduce_now, void* stream) {
+  if (!dX || !wpart || !dY || !X || !params || !T2 || !mean2 || !invstd2 || !stat_out || n_cells <= 0)
     return CG_ERR_BAD_ARG;
+  if (reduce_now && !dparams) return CG_ERR_BAD_ARG;
   if (!fused_16x4(E_, heads)) return CG_ERR_UNSUPPORTED;
   if ((((uintptr_t)dX | (uintptr_t)dY | (uintptr_t)X | (uintptr_t)keep | (uintptr_t)T2) % 16) != 0) return CG_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
@@ -931,8 +935,17 @@ extern "C" int cg_attn_block_bwd(float* dX, float* dparams, float* wpart, const 
   const int iters = (n_cells + nb * 4 - 1) / (nb * 4);
   hipLaunchKernelGGL(attn_bwd_kernel<true>, dim3(nb), dim3(256), 0, st, dX, wpart, dY, X, keep, params, n_cells, iters,
                      BwdStats{T2, mean2, invstd2, stat_out});
-  hipLaunchKernelGGL(attn_param_reduce_kernel, dim3((NPARAM + 31) / 32), dim3(256), 0, st, dparams, wpart, nb, accumulate,
-                     NPARAM);
+  if (reduce_now)
+    hipLaunchKernelGGL(attn_param_reduce_kernel, dim3((NPARAM + 31) / 32), dim3(256), 0, st, dparams, wpart, nb,
+                       accumulate, NPARAM, 0LL, 0LL);
+  return cg_launch_status();
+}
+
+extern "C" int cg_attn_param_reduce_blocks(float* dparams, long long dstride, const float* wpart, long long wstride,
+                                           int n_param_blocks, int n_cells, int accumulate, void* stream) {
+  if (!dparams || !wpart || n_param_blocks <= 0 || n_cells <= 0) return CG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(attn_param_reduce_kernel, dim3((NPARAM + 31) / 32, n_param_blocks), dim3(256), 0, (hipStream_t)stream,
+                     dparams, wpart, cg_attn_bwd_blocks(n_cells), accumulate, NPARAM, dstride, wstride);
   return cg_launch_status();
 }
 

@@ -341,10 +341,12 @@ __global__ void __launch_bounds__(TB) tok_bwd_in(float* dX, float* wpart, float*
 // dW += sum of the per-workgroup partials: workgroup 0 does dW2, workgroup 1 dW1.  1024 threads: thread (q, e) adds
 // every fourth partial of element e (its loads are independent), the four sums are added in q order through LDS.
 __global__ void __launch_bounds__(1024) tok_wgrad_reduce(float* dW2, float* dW1, const float* wpart2,
-                                                         const float* wpart1, int nblk) {
+                                                         const float* wpart1, int nblk, long long dstride = 0,
+                                                         long long wstride = 0) {
   __shared__ float part[4][TD * TD];
-  float* dst = blockIdx.x == 0 ? dW2 : dW1;
-  const float* src = blockIdx.x == 0 ? wpart2 : wpart1;
+  // blockIdx.y: one of several ResidualBlocks reduced in one launch (their weights dstride apart, partials wstride)
+  float* dst = (blockIdx.x == 0 ? dW2 : dW1) + (size_t)blockIdx.y * dstride;
+  const float* src = (blockIdx.x == 0 ? wpart2 : wpart1) + (size_t)blockIdx.y * wstride;
   const int e = threadIdx.x & 255, q = threadIdx.x >> 8;
   const int per = (nblk + 3) >> 2, b0 = q * per, b1 = min(nblk, b0 + per);
   float a = 0.f;
@@ -461,6 +463,16 @@ extern "C" int cg_tok_bwd_in(float* dX, float* wpart, float* dgamma1, float* dbe
 extern "C" int cg_tok_wgrad_reduce(float* dW2, float* dW1, const float* wpart2, const float* wpart1, int n_tok,
                                    void* stream) {
   if (!dW2 || !dW1 || !wpart2 || !wpart1 || n_tok <= 0) return CG_ERR_BAD_ARG;
-  hipLaunchKernelGGL(tok_wgrad_reduce, dim3(2), dim3(1024), 0, ST, dW2, dW1, wpart2, wpart1, cg_tok_blocks(n_tok));
+  hipLaunchKernelGGL(tok_wgrad_reduce, dim3(2), dim3(1024), 0, ST, dW2, dW1, wpart2, wpart1, cg_tok_blocks(n_tok), 0LL,
+                     0LL);
+  return cg_launch_status();
+}
+
+extern "C" int cg_tok_wgrad_reduce_blocks(float* dW2, float* dW1, long long dstride, const float* wpart2,
+                                          const float* wpart1, long long wstride, int n_res_blocks, int n_tok,
+                                          void* stream) {
+  if (!dW2 || !dW1 || !wpart2 || !wpart1 || n_res_blocks <= 0 || n_tok <= 0) return CG_ERR_BAD_ARG;
+  hipLaunchKernelGGL(tok_wgrad_reduce, dim3(2, n_res_blocks), dim3(1024), 0, ST, dW2, dW1, wpart2, wpart1,
+                     cg_tok_blocks(n_tok), dstride, wstride);
   return cg_launch_status();
 }

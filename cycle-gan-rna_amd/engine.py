@@ -262,6 +262,22 @@ class GenPass:
         self.d16 = [Z(T, D), Z(T, D)]
         self.dml = Z(B, 2 * L)
         self.attn_ws = Z(max(ops.attn_bwd_ws(B, D, self.heads), 1))   # raises for a geometry that is not built
+        # the parameter-gradient partials of every block kept apart and reduced in two launches at the end of the
+        # latent chain's backward instead of two per block (needs the blocks' tensors at equal distances in the arena)
+        self.defer_reduce = False
+        if self.fused_block and hasattr(ops, "latent_param_reduce") and not os.environ.get("CGRNA_NO_DEFERRED_REDUCE"):
+            def steps(ts):
+                d = {ts[k + 1].data_ptr() - ts[k].data_ptr() for k in range(len(ts) - 1)}
+                return len(d) <= 1 and all(x % 16 == 0 for x in d)
+            pres = [f"residual_attention_blocks.{bi}" for bi in range(self.nb)]
+            w2 = [net.G[q + ".0.block.3.weight"] for q in pres]
+            w1 = [net.G[q + ".0.block.0.weight"] for q in pres]
+            same = len({w2[k + 1].data_ptr() - w2[k].data_ptr() for k in range(self.nb - 1)} |
+                       {w1[k + 1].data_ptr() - w1[k].data_ptr() for k in range(self.nb - 1)}) <= 1
+            if steps([self._attn("g", bi) for bi in range(self.nb)]) and steps(w2) and steps(w1) and same:
+                self.defer_reduce = True
+                self.attn_ws_b = Z(self.nb, self.attn_ws.numel())
+                self.tok_wpart_b = [Z(self.nb, self.tok_wpart[0].numel()), Z(self.nb, self.tok_wpart[1].numel())]
         self.eps = None
         self.labels = None
         self.x = None
@@ -519,16 +535,18 @@ class GenPass:
             (s1, s2) = self.rb_stats[bi]
             dy = self.dz[1 - cur][:b].view(t, self.D)
             zin = self.z[bi][:b].view(t, self.D)
+            defer = self.defer_reduce
             if self.fused_block:        # the attention's backward also sums what the BatchNorm backward below needs
                 s3 = self.tok_stat[2]
-                ops.attn_block_bwd(dy, self._attn("g", bi), self.attn_ws, dz, self.y[bi][:t], self.keep[bi],
-                                   self._attn("p", bi), self.heads, True, self.t2[bi][:t], s2[0], s2[1], s3)
+                ops.attn_block_bwd(dy, self._attn("g", bi), self.attn_ws_b[bi] if defer else self.attn_ws, dz,
+                                   self.y[bi][:t], self.keep[bi], self._attn("p", bi), self.heads, True,
+                                   self.t2[bi][:t], s2[0], s2[1], s3, reduce_now=not defer)
             else:
                 ops.attn_bwd(dy, self._attn("g", bi), self.attn_ws, dz, self.y[bi][:t], self.keep[bi], self._attn("p", bi),
                              self.heads, True)
             if self.fused_tok:
                 s3, s4 = self.tok_stat[2], self.tok_stat[3]
-                wp2, wp1 = self.tok_wpart
+                wp2, wp1 = (self.tok_wpart_b[0][bi], self.tok_wpart_b[1][bi]) if defer else self.tok_wpart
                 g1buf = self.d16[0][:t]
                 mid = (self.t2[bi][:t], self.r[bi][:t], self.t1[bi][:t])
                 if self.fused_block:
@@ -543,7 +561,8 @@ class GenPass:
                 ops.tok_bwd_in(dy, wp1, G[pre + ".0.block.1.weight"], G[pre + ".0.block.1.bias"], g1buf,
                                self.t1[bi][:t], zin, dy, s4, s1[0], s1[1], P[pre + ".0.block.1.weight"],
                                P[pre + ".0.block.0.weight"])
-                ops.tok_wgrad_reduce(G[pre + ".0.block.3.weight"], G[pre + ".0.block.0.weight"], wp2, wp1, t)
+                if not defer:
+                    ops.tok_wgrad_reduce(G[pre + ".0.block.3.weight"], G[pre + ".0.block.0.weight"], wp2, wp1, t)
             else:           # the same chain through the general kernels; dy ends as the gradient w.r.t. zin
                 dt, dr = self.d16[0][:t], self.d16[1][:t]
                 ops.bn_bwd(dt, dy, self.t2[bi][:t], None, None, s2[0], s2[1], P[pre + ".0.block.4.weight"],
@@ -556,6 +575,13 @@ class GenPass:
                 ops.gemm(dy, dt, P[pre + ".0.block.0.weight"], False, False, accumulate=True)
             cur = 1 - cur
             dz = dy
+        if self.defer_reduce:
+            pres = [f"residual_attention_blocks.{bi}" for bi in range(self.nb)]
+            done = ops.latent_param_reduce([self._attn("g", bi) for bi in range(self.nb)], self.attn_ws_b,
+                                           [G[q + ".0.block.3.weight"] for q in pres],
+                                           [G[q + ".0.block.0.weight"] for q in pres], self.tok_wpart_b[0],
+                                           self.tok_wpart_b[1], b)
+            assert done
         dz0 = self.dz[cur][:b]
         dml = self.dml[:b]
         coef, idx, w = kl if kl is not None else (None, 0, 0.0)

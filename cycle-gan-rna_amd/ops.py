@@ -836,8 +836,10 @@ class HipOps:
         st = self.lib.cg_attn_ln_fwd(_ptr(Y), _ptr(X), _ptr(keep), _ptr(params), n_cells, E, heads, self._stream())
         _lib.check(st, "cg_attn_ln_fwd")
 
-    def attn_block_bwd(self, dX, dparams, ws, dY, X, keep, params, heads, accumulate, T2, mean2, invstd2, stat_out):
-        """attn_bwd + tok_bn_bwd_stats of the ResidualBlock below: attn_bwd_blocks(n_cells) partials into stat_out."""
+    def attn_block_bwd(self, dX, dparams, ws, dY, X, keep, params, heads, accumulate, T2, mean2, invstd2, stat_out,
+                       reduce_now=True):
+        """attn_bwd + tok_bn_bwd_stats of the ResidualBlock below: attn_bwd_blocks(n_cells) partials into stat_out.
+        reduce_now=False: the parameter gradients stay as per-workgroup partials in ws (latent_param_reduce)."""
         E = X.shape[-1]
         n_cells = X.numel() // (16 * E)
         assert ws.numel() >= self.attn_bwd_ws(n_cells, E, heads) and dparams.numel() == attn_nparam(E)
@@ -845,8 +847,30 @@ class HipOps:
         assert stat_out.numel() >= self.attn_bwd_blocks(n_cells) * 32
         st = self.lib.cg_attn_block_bwd(_ptr(dX), _ptr(dparams), _ptr(ws), _ptr(dY), _ptr(X), _ptr(keep), _ptr(params),
                                         n_cells, E, heads, int(accumulate), _ptr(T2), _ptr(mean2), _ptr(invstd2),
-                                        _ptr(stat_out), self._stream())
+                                        _ptr(stat_out), int(reduce_now), self._stream())
         _lib.check(st, "cg_attn_block_bwd")
+
+    def latent_param_reduce(self, attn_grads, attn_ws, tok_dW2, tok_dW1, wp2, wp1, n_cells):
+        """The parameter-gradient reduces of all residual-attention blocks of a backward pass in two launches.
+        attn_grads / tok_dW2 / tok_dW1: per block, the gradient tensors (views of one arena, at equal distances);
+        attn_ws, wp2, wp1: (blocks, partials) workspaces the backward kernels filled.  Returns False (nothing
+        launched) when the blocks' tensors are not at equal distances."""
+        nb = len(attn_grads)
+
+        def stride(ts):
+            d = [(ts[k + 1].data_ptr() - ts[k].data_ptr()) for k in range(nb - 1)]
+            return (d[0] // 4 if d else 0) if all(x == d[0] and x % 4 == 0 for x in d) else None
+        sa, s2, s1 = stride(attn_grads), stride(tok_dW2), stride(tok_dW1)
+        if sa is None or s2 is None or s1 is None or s2 != s1:
+            return False
+        assert attn_ws.shape[0] == nb and wp2.shape[0] == nb and wp1.shape[0] == nb and attn_ws.is_contiguous()
+        st = self.lib.cg_attn_param_reduce_blocks(_ptr(attn_grads[0]), sa, _ptr(attn_ws), attn_ws.stride(0), nb, n_cells,
+                                                  1, self._stream())
+        _lib.check(st, "cg_attn_param_reduce_blocks")
+        st = self.lib.cg_tok_wgrad_reduce_blocks(_ptr(tok_dW2[0]), _ptr(tok_dW1[0]), s2, _ptr(wp2), _ptr(wp1),
+                                                 wp2.stride(0), nb, n_cells * 16, self._stream())
+        _lib.check(st, "cg_tok_wgrad_reduce_blocks")
+        return True
 
     def attn_bwd_blocks(self, n_cells):
         return self.lib.cg_attn_bwd_blocks(n_cells)

@@ -550,12 +550,22 @@ int cg_attn_ln_fwd(float* Y, const float* X, const float* keep, const float* par
  * cg_attn_block_bwd: cg_attn_ln_bwd that also takes the first step of the ResidualBlock's backward below it
  * (cg_tok_bn_bwd_stats): with g = dX it writes cg_attn_bwd_blocks(n_cells) x 32 partial sums of g and
  * g * (T2 - mean2) * invstd2 to stat_out, which cg_tok_bwd_mid_from (cg_tok_bwd_mid reading n_stat_in partials) adds
- * up.  E = 16 with 4 heads only.
+ * up.  E = 16 with 4 heads only.  reduce_now = 0: the partial parameter gradients stay in wpart (dparams is not
+ * touched) for cg_attn_param_reduce_blocks.
  */
 int cg_attn_block_blocks(int n_cells);
 int cg_attn_block_bwd(float* dX, float* dparams, float* wpart, const float* dY, const float* X, const float* keep,
                       const float* params, int n_cells, int E, int heads, int accumulate, const float* T2,
-                      const float* mean2, const float* invstd2, double* stat_out, void* stream);
+                      const float* mean2, const float* invstd2, double* stat_out, int reduce_now, void* stream);
+/* The parameter-gradient reduces of several residual-attention blocks in one launch each, for callers that kept the
+ * blocks' per-workgroup partial sums apart (cg_attn_block_bwd with reduce_now = 0 and its own wpart per block;
+ * cg_tok_bwd_mid / cg_tok_bwd_in with their own wpart per block): block k reads wpart + k * wstride and adds into
+ * dparams + k * dstride (dW2 / dW1 + k * dstride), strides in floats - the blocks of a generator lie at equal
+ * distances in a flat parameter arena.  The same sums as cg_attn_ln_bwd's reduce / cg_tok_wgrad_reduce per block. */
+int cg_attn_param_reduce_blocks(float* dparams, long long dstride, const float* wpart, long long wstride,
+                                int n_param_blocks, int n_cells, int accumulate, void* stream);
+int cg_tok_wgrad_reduce_blocks(float* dW2, float* dW1, long long dstride, const float* wpart2, const float* wpart1,
+                               long long wstride, int n_res_blocks, int n_tok, void* stream);
 int cg_tok_bwd_mid_from(float* G1, double* stat_out, float* wpart, float* dgamma2, float* dbeta2, const float* dY,
                         const float* T2, const float* R, const float* T1, const double* stat_in, int n_stat_in,
                         const float* mean2, const float* invstd2, const float* gamma2, const float* W2,
