@@ -43,6 +43,12 @@ class GradSync:
         # call - and, with two processes sharing one GPU, now and then even behind a drained stream.  So for gloo the
         # staging is done here: device -> host copy, all_reduce of the host tensor, copy back.
         self.host_staged = self.enabled and self.is_cuda and dist.get_backend() == "gloo"
+        # RCCL averages inside the collective (every rank's addend is scaled by 1/world before the sum).  For a power
+        # of two that scaling is exact, so the result has the bits of sum-then-scale and the scaling launch per bucket
+        # (a read and a write of every gradient byte) goes away; any other world size, and gloo, keep sum-then-scale.
+        self.avg_in_collective = (self.enabled and self.is_cuda and dist.get_backend() == "nccl"
+                                  and self.world & (self.world - 1) == 0
+                                  and not os.environ.get("CGRNA_DDP_SUM_THEN_SCALE"))
 
     def launch(self, flat_grad, ranges=None):
         """Start averaging `flat_grad` (a contiguous 1-D tensor) over the ranks, or only its element ranges
@@ -69,8 +75,11 @@ class GradSync:
                     dist.all_reduce(host, op=dist.ReduceOp.SUM)
                     chunk.copy_(host.mul_(1.0 / self.world))
                     continue
-                # sum + scale rather than ReduceOp.AVG: identical on RCCL, and also valid on gloo, which lets
-                # the device code path be exercised by two ranks sharing one GPU
+                if self.avg_in_collective:
+                    dist.all_reduce(chunk, op=dist.ReduceOp.AVG)
+                    continue
+                # sum + scale: also valid on gloo, which lets the device code path be exercised by two ranks
+                # sharing one GPU
                 dist.all_reduce(chunk, op=dist.ReduceOp.SUM)
                 chunk.mul_(1.0 / self.world)
         done = torch.cuda.Event()
