@@ -6,6 +6,7 @@ operands of a product come from HBM and the choice that wins there can be a diff
 candidate is forced through CGRNA_GEMM_OVERRIDE and timed where it is used.  Prints the table rows of the winners.
 
     python tools/tune_in_step.py [bf16] [--thresh=0.97] [--genes=5000] [--batch=512] > gpurun_out/in_step_f32.csv
+    python tools/tune_in_step.py --dump --shapes=512,5000,1024,0,0,0:512,5000,512,0,1,0     (these shapes only, every candidate's time)
 """
 import os
 os.environ.setdefault("CGRNA_GEMM_TUNING", "1")   # cg_gemm looks at its tuning hooks only when this is set at its first call
@@ -69,6 +70,10 @@ measure(1)
 base = measure(3)
 want = 1 if half else 0
 shapes = sorted((k for k in base if (k[6] & 1) == want and min(k[0], k[1]) > 2 and k[2] > 16), key=lambda k: -base[k][0] * base[k][1])
+for _a in sys.argv[1:]:
+    if _a.startswith("--shapes="):
+        _only = {tuple(int(v) for v in t.split(",")) for t in _a.split("=", 1)[1].split(":")}
+        shapes = [k for k in shapes if tuple(k[:6]) in _only]
 total_gain = 0.0
 for shape in shapes:
     M, N, K, ta, tb, acc, dt = shape
