@@ -596,6 +596,32 @@ __global__ void __launch_bounds__(256 * KW) gemm_bf16_kernel(GemmArgs g) {
   }
 
   // 16x16 accumulator: col = lane & 15, row = 4 * (lane >> 4) + reg
+  if (fused && g.vec4) {
+    // as in finish_f32: the tile goes through LDS and leaves for the slab as write-through 16-byte pieces of rows
+    constexpr int LDT = BN + 4;
+    static_assert(BM * LDT * 4 <= 2 * (A_ELEMS + B_ELEMS) * 2, "the output tile does not fit in the staging LDS");
+    float* tl = reinterpret_cast<float*>(smem);
+    __syncthreads();      // the last slab (or the accumulator exchange) has been read
+    if (kg == 0) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) tl[(wm + 16 * i + 4 * lg + r) * LDT + wn + 16 * j + lr] = acc[i][j][r];
+    }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rs = make_rsrc(g.ws, 0xfffffff0u);
+    const size_t slab = (size_t)split * g.M * g.N;
+    for (int idx = threadIdx.x; idx < BM * BN / 4; idx += NT) {
+      const int r = idx / (BN / 4), c = 4 * (idx % (BN / 4)), row = bm + r, col = bn + c;
+      if (row < g.M && col < g.N)
+        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<const u32x4*>(tl + r * LDT + c), rs,
+                                               (unsigned)((slab + (size_t)row * g.N + col) * 4), 0, 16);   // 16: sc1
+    }
+    split_tail<BM, BN, NT>(g, tile, bm, bn, reinterpret_cast<int*>(tl + BN), split, tl);   // the flag in the padding of the tile's first row
+    return;
+  }
   float* wsp = gridDim.y > 1 ? g.ws + (size_t)split * g.M * g.N : nullptr;
   if (kg == 0) {
 #pragma unroll
