@@ -132,8 +132,9 @@ class HipOps:
     # -- hardware queues and forked HIP graphs --------------------------------------
     @staticmethod
     def forked_graphs_supported():
-        """(ok, reason): False when the process's HIP settings leave a forked graph fewer hardware queues than
-        internal streams (GPU_MAX_HW_QUEUES below 4, or more graph streams than queues asked for with
+        """(ok, reason): False when the process's HIP settings give more hardware queues than four (slower, see
+        below) or leave a forked graph fewer hardware queues than internal streams (GPU_MAX_HW_QUEUES below 4, or more
+        graph streams than queues asked for with
         DEBUG_HIP_FORCE_GRAPH_QUEUES): two of its streams then always share the launch stream's queue, which the
         runtime's launch code does not survive: at every launch it uses all but one of the graph's (up to four)
         internal streams, skipping those that share the launch stream's hardware queue, without checking that enough
@@ -148,6 +149,12 @@ class HipOps:
         if queues < 4 or graph_streams > queues:
             return False, ("GPU_MAX_HW_QUEUES=%d with %d graph streams: a HIP graph with parallel branches cannot be "
                            "launched safely" % (queues, graph_streams))
+        if queues > 4:
+            # the branches of a replayed graph then land on queues that the hardware time-slices against each other
+            # instead of running their kernels back to back: 3.8 / 4.7 / 5.3 ms per iteration with 6 / 8 / 16 queues
+            # (5000 genes, batch 512) against 3.5 ms for the same step captured on one stream and 2.55 ms with four
+            return False, ("GPU_MAX_HW_QUEUES=%d: with more than four hardware queues the branches of a replayed graph "
+                           "are time-sliced against each other and run slower than one stream" % queues)
         return True, ""
 
     # -- measurement: HIP events around every GEMM launch, on the launch stream ----------

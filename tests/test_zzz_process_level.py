@@ -41,3 +41,11 @@ def test_fewer_hardware_queues_than_graph_branches():
     p = _run([os.path.join(ROOT, "tools", "stress_first_run.py")], 280, STRESS_EPOCHS="3", GPU_MAX_HW_QUEUES="2")
     _stress_ok(p)
     assert "captured on one stream" in p.stderr
+
+
+def test_more_hardware_queues_than_four():
+    """GPU_MAX_HW_QUEUES=8: forked graphs would run (slower than one stream: their branches are time-sliced), so the
+    step is captured on one stream (with a warning) - same bits as the eager run."""
+    p = _run([os.path.join(ROOT, "tools", "stress_first_run.py")], 280, STRESS_EPOCHS="3", GPU_MAX_HW_QUEUES="8")
+    _stress_ok(p)
+    assert "captured on one stream" in p.stderr
