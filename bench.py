@@ -179,14 +179,14 @@ def big_shard(dev, genes=20000, batch=BATCH, steps=20):
     def b(i):
         s = (i % 4) * batch
         return xm[s:s + batch], xh[s:s + batch], lm[s:s + batch], lh[s:s + batch]
-    for i in range(2 * NB_CRITIC + 2 + 4):
+    def one(i):
         noise.begin_step()
         eng.iteration(i, *b(i), noise, nxt=b(i + 1), metrics=False)
+    n0 = settle_graphs(eng, one)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(steps):
-        noise.begin_step()
-        eng.iteration(i, *b(i), noise, nxt=b(i + 1), metrics=False)
+    for i in range(n0, n0 + steps):
+        one(i)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     losses = {**eng.d_losses(), **eng.g_losses()}
@@ -195,6 +195,30 @@ def big_shard(dev, genes=20000, batch=BATCH, steps=20):
     return dict(genes=genes, batch_per_gpu=batch, dtype="f32", steps=steps, ms_per_step=dt / steps * 1e3,
                 value=batch * steps / dt, unit="cells/s",
                 gflop_per_iteration=algorithmic_gflop_per_cell_iteration(genes) * batch)
+
+
+def settle_graphs(eng, step, warmup=0):
+    """Setup, untimed: every HIP graph of the schedule runs eagerly on its first call, is captured on its second and
+    replayed from its third on, and the first replays of a graph are slower than the later ones.  The lookahead
+    schedule uses six graphs, some of them once in two nb_critic cycles, so whole cycles are run until no new graph
+    has appeared and each has been called four times.  Returns the index of the next iteration: the warm-up and the
+    timed steps carry on from it (an index that jumps back makes the schedule issue a forward pass again that it had
+    issued ahead, through graphs that the steady state never uses), padded so that the timed region starts with an
+    iteration that holds a generator step, whatever `warmup` is.  step(i) runs iteration i."""
+    n = 0
+    if eng.use_graphs:
+        for _ in range(16):
+            known = len(eng._graphs)
+            for _ in range(NB_CRITIC):
+                step(n)
+                n += 1
+            calls = [g["calls"] for g in eng._graphs.values()]
+            if len(eng._graphs) == known and calls and min(calls) >= 4:
+                break
+        for _ in range(-warmup % NB_CRITIC):
+            step(n)
+            n += 1
+    return n
 
 
 def _profile_json(name):
@@ -316,15 +340,12 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    if eng.use_graphs:
-        # every graph runs eagerly on its first call and is captured on its second; neither is timed
-        for i in range(2 * NB_CRITIC + 2 if eng.lookahead else 2):
-            step(0 if not eng.lookahead else i)
-    for i in range(a.warmup):
+    n0 = settle_graphs(eng, step, a.warmup)
+    for i in range(n0, n0 + a.warmup):
         step(i)
     fence()
     t0 = time.perf_counter()
-    for i in range(a.steps):
+    for i in range(n0 + a.warmup, n0 + a.warmup + a.steps):
         step(i)
     fence()
     dt = time.perf_counter() - t0
@@ -434,13 +455,12 @@ def main():
             s = (i % 16) * B
             noise.begin_step()
             eng16.iteration(i, *batch(i), noise, nxt=batch(i + 1) if eng16.lookahead else None, metrics=False)
-        for i in range((2 * NB_CRITIC + 2 if eng16.lookahead else 2) if eng16.use_graphs else 0):
-            step16(i if eng16.lookahead else 0)
-        for i in range(a.warmup):
+        n16 = settle_graphs(eng16, step16, a.warmup)
+        for i in range(n16, n16 + a.warmup):
             step16(i)
         fence()
         t0 = time.perf_counter()
-        for i in range(a.steps):
+        for i in range(n16 + a.warmup, n16 + a.warmup + a.steps):
             step16(i)
         fence()
         dt16 = time.perf_counter() - t0
