@@ -2001,6 +2001,13 @@ class StepEngine(EngineBase):
             passes = self.gen_a if mode == "g" else self.gen_d[1 - s]
             # the generator step's first forward follows the critic step's forward of the same batch (set s)
             src = self.gen_d[s] if (mode == "g" and self.reuse_encoder) else {}
+            # The critics' part is issued first and the lanes' forwards after it: the streams make them run side by
+            # side either way, but the order of issue is the order of the captured graph's nodes, and with the critics
+            # (the longer chain) first the replay takes 2.568 against 2.578 ms.  The draws keep their order (the
+            # critics' noise was drawn above).  Captured on one stream the forward stays in front, as in a plain step.
+            critics_first = not single
+            if critics_first:
+                self._d_crit_set(s)(noise)
             with self._Lane(self, noise, lanes[0]):
                 out_h = passes["g_m2h"].forward(mouse, mouse_cat, noise, encoder_of=src.get("g_m2h"))
             with self._Lane(self, noise, lanes[1]):
@@ -2009,7 +2016,8 @@ class StepEngine(EngineBase):
                 self._g_state = (mouse, human, mouse_cat, human_cat, dict(fh=out_h, fm=out_m), noise)
             else:
                 self._set_d_state(1 - s, (mouse, human, mouse_cat, human_cat, noise, out_h, out_m))
-            self._d_crit_set(s)(noise)
+            if not critics_first:
+                self._d_crit_set(s)(noise)
             for st in () if single else lanes:
                 self._after(main, st)
             if mode == "g":
