@@ -200,20 +200,21 @@ def big_shard(dev, genes=20000, batch=BATCH, steps=20):
 def settle_graphs(eng, step, warmup=0):
     """Setup, untimed: every HIP graph of the schedule runs eagerly on its first call, is captured on its second and
     replayed from its third on, and the first replays of a graph are slower than the later ones.  The lookahead
-    schedule uses six graphs, some of them once in two nb_critic cycles, so whole cycles are run until no new graph
-    has appeared and each has been called four times.  Returns the index of the next iteration: the warm-up and the
+    schedule uses six graphs, some of them once in two nb_critic cycles, so pairs of cycles are run until no new graph
+    has appeared and each graph in use has been called four times.  Returns the index of the next iteration: the warm-up and the
     timed steps carry on from it (an index that jumps back makes the schedule issue a forward pass again that it had
     issued ahead, through graphs that the steady state never uses), padded so that the timed region starts with an
     iteration that holds a generator step, whatever `warmup` is.  step(i) runs iteration i."""
     n = 0
     if eng.use_graphs:
         for _ in range(16):
-            known = len(eng._graphs)
-            for _ in range(NB_CRITIC):
+            before = {k: g["calls"] for k, g in eng._graphs.items()}
+            for _ in range(2 * NB_CRITIC):      # two cycles: the workspace sets of the lookahead alternate
                 step(n)
                 n += 1
-            calls = [g["calls"] for g in eng._graphs.values()]
-            if len(eng._graphs) == known and calls and min(calls) >= 4:
+            # the graphs these cycles used (one that only the very first step of a run uses does not hold things up)
+            used = [g["calls"] for k, g in eng._graphs.items() if g["calls"] != before.get(k)]
+            if len(eng._graphs) == len(before) and used and min(used) >= 4:
                 break
         for _ in range(-warmup % NB_CRITIC):
             step(n)
