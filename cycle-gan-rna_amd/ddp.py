@@ -50,12 +50,16 @@ class GradSync:
                                   and self.world & (self.world - 1) == 0
                                   and not os.environ.get("CGRNA_DDP_SUM_THEN_SCALE"))
 
-    def launch(self, flat_grad, ranges=None):
+    def launch(self, flat_grad, ranges=None, then=None):
         """Start averaging `flat_grad` (a contiguous 1-D tensor) over the ranks, or only its element ranges
         [(lo, hi), ...], whose producer kernels have been enqueued on the current stream.  Buckets of at most
-        bucket_bytes go out on the side stream in the order given; wait() joins them."""
+        bucket_bytes go out on the side stream in the order given; wait() joins them.  `then` (a callable) is run
+        behind the buckets with the side stream current - work that needs nothing but the averaged ranges, such
+        as their optimizer step, which then runs beside whatever the calling stream goes on with; wait() covers it.
+        Returns the event that marks the end of this call's work (None for host tensors, which are done on
+        return)."""
         if not self.enabled:
-            return
+            return None
         if ranges is None:
             ranges = [(0, flat_grad.numel())]
         chunks = [flat_grad[s:min(s + self.bucket_elems, hi)] for lo, hi in ranges if hi > lo
@@ -64,7 +68,9 @@ class GradSync:
             for chunk in chunks:
                 dist.all_reduce(chunk, op=dist.ReduceOp.SUM)
                 chunk.div_(self.world)
-            return
+            if then is not None:
+                then()
+            return None
         ready = torch.cuda.Event()
         ready.record(torch.cuda.current_stream(self.device))
         self.comm.wait_event(ready)
@@ -82,9 +88,12 @@ class GradSync:
                 # sharing one GPU
                 dist.all_reduce(chunk, op=dist.ReduceOp.SUM)
                 chunk.mul_(1.0 / self.world)
+            if then is not None:
+                then()
         done = torch.cuda.Event()
         done.record(self.comm)
         self.pending.append(done)
+        return done
 
     def wait(self):
         """Make the current stream wait for every launched bucket."""

@@ -1461,7 +1461,7 @@ class StepEngine(EngineBase):
             pend = self._d_pending_lr is not None
             self._run_parts("d", b, ins, noise, [("graph", self._d_gen),
                                                  ("eager", self._d_wait_pending if pend else None),
-                                                 ("graph", self._d_apply_then_critics if pend else self._d_critics),
+                                                 ("graph", self._d_critics),
                                                  ("eager", self._d_launch_comm)])
 
     def _run_parts(self, kind, b, tensors, noise, parts):
@@ -1498,20 +1498,20 @@ class StepEngine(EngineBase):
 
     def _d_wait_pending(self):
         self.sync.wait()
-        self._begin_opt(self.arena_d, self._d_pending_lr)
-
-    def _d_apply_pending(self):
-        self._adam(self.arena_d)
 
     def _d_launch_comm(self):
-        self.sync.launch(self.arena_d.g)
+        # the critics' optimizer step rides on the communication stream behind the buckets: it needs nothing but the
+        # averaged gradients, and runs beside the generators' forward passes that the calling stream issues next
+        def update():
+            self._begin_opt(self.arena_d, self.lr_d)
+            self._adam(self.arena_d)
+        self.sync.launch(self.arena_d.g, then=update)
         self._d_pending_lr = self.lr_d
 
     def flush(self):
-        """Apply a critic update that is still in flight (several ranks); call before reading critic parameters."""
+        """Wait for a critic update that is still in flight (several ranks); call before reading critic parameters."""
         if self._d_pending_lr is not None:
             self._d_wait_pending()
-            self._adam(self.arena_d)
             self._d_pending_lr = None
 
     def _d_gen(self, mouse, human, mouse_cat, human_cat, noise):
@@ -1614,7 +1614,7 @@ class StepEngine(EngineBase):
         self._run_parts("g" if self._g_encoder_of is None else "ge", b, (mouse, human, mouse_cat, human_cat), noise,
                         [("graph", self._g_first),
                          ("eager", self._d_wait_pending_clear if multi else None),   # the critics are needed from here on
-                         ("graph", self._d_apply_then_g_rest if multi else self._g_rest),
+                         ("graph", self._g_rest),
                          ("eager", self._g_loss_comm if self.sync.enabled else None),
                          ("graph", self._g_backward),
                          # several ranks: the decoders' gradients (complete first) are averaged while the rest of the
@@ -1622,17 +1622,9 @@ class StepEngine(EngineBase):
                          ("eager", self._g_grad_comm_decoders if self.sync.enabled else None),
                          ("graph", self._g_backward_rest if self.sync.enabled else None),
                          ("eager", self._g_grad_comm_rest if self.sync.enabled else None),
-                         ("graph", self._g_update)])
-
-    # Several ranks: the deferred critic update shares a HIP graph with the device work that follows it (one graph
-    # launch less per step than a graph of its own).
-    def _d_apply_then_critics(self):
-        self._d_apply_pending()
-        self._d_critics()
-
-    def _d_apply_then_g_rest(self):
-        self._d_apply_pending()
-        self._g_rest()
+                         # (several ranks: nothing left for the device here, the optimizer step went out behind the
+                         # all-reduces)
+                         ("eager" if self.sync.enabled else "graph", self._g_update)])
 
     def _d_wait_pending_clear(self):
         self._d_wait_pending()
@@ -1802,12 +1794,22 @@ class StepEngine(EngineBase):
         # (the cycle passes, which add to the same tensors, ran before): 2 x 23 MB of the 151 MB at 5000 genes
         # travel beside the latent blocks' and the encoder's backward; the encoder gradients, the last to be
         # complete and 2 x 52 MB, are exposed
-        self.sync.launch(self.arena_g.g, self._g_decoder_ranges())
+        # ... and their optimizer step follows them on the communication stream, beside the same backward work
+        ranges = self._g_decoder_ranges()
+        self.sync.launch(self.arena_g.g, ranges, then=lambda: [self._adam(self.arena_g, lo, hi) for lo, hi in ranges])
 
     def _g_grad_comm_rest(self):
         (a0, a1), (b0, b1) = self._g_decoder_ranges()
-        self.sync.launch(self.arena_g.g, [(0, a0), (a1, b0), (b1, self.arena_g.n)])
-        self.sync.wait()
+        # the rest range by range: a range's optimizer step is issued on the calling stream as soon as the range has
+        # been averaged, and runs while the next range travels
+        rest = [(lo, hi) for lo, hi in [(0, a0), (a1, b0), (b1, self.arena_g.n)] if hi > lo]
+        done = [self.sync.launch(self.arena_g.g, [r]) for r in rest]
+        cur = torch.cuda.current_stream(self.ops.device) if self.ops.device.type == "cuda" else None
+        for (lo, hi), ev in zip(rest, done):
+            if ev is not None:
+                cur.wait_event(ev)
+            self._adam(self.arena_g, lo, hi)
+        self.sync.wait()        # the decoders' ranges and their optimizer step
 
     _adam_stage_ranges = None
 
@@ -1834,8 +1836,8 @@ class StepEngine(EngineBase):
         ops = self.ops
         o = self._g_state[4]
         fake_human, fake_mouse = o["fh"], o["fm"]
-        if self.sync.enabled:       # one rank: done range by range inside the backward branches (_g_backward)
-            self._adam(self.arena_g)
+        # the optimizer step: one rank - range by range inside the backward branches (_g_backward); several ranks -
+        # range by range behind each range's all-reduce (_g_grad_comm_decoders, _g_grad_comm_rest)
         self.fake_human, self.fake_mouse = fake_human, fake_mouse
 
     def set_loss_weights(self, weights):
