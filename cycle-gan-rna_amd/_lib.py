@@ -82,6 +82,7 @@ SIGNATURES = {
     "cg_reduce_centroid_sq": ([P, P, P, I, P, I, P, I, I, I, I, P], I),
     "cg_reduce_kl": ([P, P, P, I, I, I, P], I),
     "cg_colsum": ([P, P, I, I, I, F, I, P], I),
+    "cg_copy4": ([P, P, L, P, P, L, P, P, L, P, P, L, P], I),
     "cg_colsum3": ([P, P, I, I, I, F, I, P, P, I, I, I, F, I, P, P, I, I, I, F, I, P], I),
     "cg_reduce_sum_seg": ([P, P, P, I, I, I, I, P], I),
     "cg_reduce_sqdiff": ([P, P, P, I, P, I, I, I, P], I),

@@ -867,6 +867,56 @@ extern "C" int cg_colsum(float* out, const float* X, int ldx, int M, int N, floa
   return cg_launch_status();
 }
 
+// Up to four contiguous copies in one launch: blockIdx.y names the job, its workgroups stride over 16-byte pieces
+// (4-byte words when an address or a size is not a multiple of 16).
+struct CopyJobs {
+  void* dst[4];
+  const void* src[4];
+  unsigned long long bytes[4];
+  int wide[4];
+};
+__global__ void __launch_bounds__(256) copy4_kernel(CopyJobs j) {
+  const int k = blockIdx.y;
+  const size_t i0 = (size_t)blockIdx.x * 256 + threadIdx.x, step = (size_t)gridDim.x * 256;
+  if (j.wide[k]) {
+    const uint4* s = static_cast<const uint4*>(j.src[k]);
+    uint4* d = static_cast<uint4*>(j.dst[k]);
+    const size_t n = j.bytes[k] >> 4;
+    for (size_t i = i0; i < n; i += step) d[i] = s[i];
+  } else {
+    const uint32_t* s = static_cast<const uint32_t*>(j.src[k]);
+    uint32_t* d = static_cast<uint32_t*>(j.dst[k]);
+    const size_t n = j.bytes[k] >> 2;
+    for (size_t i = i0; i < n; i += step) d[i] = s[i];
+  }
+}
+
+extern "C" int cg_copy4(void* dst0, const void* src0, long long bytes0, void* dst1, const void* src1, long long bytes1,
+                        void* dst2, const void* src2, long long bytes2, void* dst3, const void* src3, long long bytes3,
+                        void* stream) {
+  void* ds[4] = {dst0, dst1, dst2, dst3};
+  const void* ss[4] = {src0, src1, src2, src3};
+  const long long bs[4] = {bytes0, bytes1, bytes2, bytes3};
+  CopyJobs j{};
+  int n = 0;
+  long long most = 0;
+  for (int k = 0; k < 4; ++k) {
+    if (bs[k] == 0) continue;       // an unused job
+    if (bs[k] < 0 || bs[k] % 4 || !ds[k] || !ss[k] || (uintptr_t)ds[k] % 4 || (uintptr_t)ss[k] % 4) return CG_ERR_BAD_ARG;
+    j.dst[n] = ds[k];
+    j.src[n] = ss[k];
+    j.bytes[n] = (unsigned long long)bs[k];
+    j.wide[n] = bs[k] % 16 == 0 && (uintptr_t)ds[k] % 16 == 0 && (uintptr_t)ss[k] % 16 == 0;
+    most = bs[k] > most ? bs[k] : most;
+    ++n;
+  }
+  if (n == 0) return CG_OK;
+  long long blocks = (most / 16 + 255) / 256;
+  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  hipLaunchKernelGGL(copy4_kernel, dim3((unsigned)blocks, n), dim3(256), 0, ST, j);
+  return cg_launch_status();
+}
+
 extern "C" int cg_colsum3(float* out0, const float* X0, int ldx0, int M0, int N0, float scale0, int accumulate0,
                           float* out1, const float* X1, int ldx1, int M1, int N1, float scale1, int accumulate1,
                           float* out2, const float* X2, int ldx2, int M2, int N2, float scale2, int accumulate2,

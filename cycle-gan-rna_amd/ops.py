@@ -643,6 +643,20 @@ class HipOps:
         st = self.lib.cg_colsum(_ptr(out), _ptr(X), _ld(X), M, N, float(scale), int(accumulate), self._stream())
         _lib.check(st, "cg_colsum")
 
+    def copy_many(self, pairs):
+        """[(dst, src), ...]: dst <- src for contiguous device tensors of equal size and dtype, four per launch."""
+        for i in range(0, len(pairs), 4):
+            args = []
+            for k in range(4):
+                if i + k < len(pairs):
+                    dst, src = pairs[i + k]
+                    assert dst.is_contiguous() and src.is_contiguous() and dst.dtype == src.dtype and \
+                        dst.numel() == src.numel() and dst.device == src.device == self.device
+                    args += [dst.data_ptr(), src.data_ptr(), dst.numel() * dst.element_size()]
+                else:
+                    args += [0, 0, 0]
+            _lib.check(self.lib.cg_copy4(*args, self._stream()), "cg_copy4")
+
     def colsum_multi(self, jobs):
         """[(out, X, scale, accumulate), ...]: colsum of every job, three per launch."""
         for i in range(0, len(jobs), 3):

@@ -393,6 +393,12 @@ int cg_reduce_kl(float* parts, int* nparts, const float* ml, int ldml, int M, in
 /* out[n] (+)= scale * sum_m X[m,n]: column means (feature matching :368,:372; scale = 1/M) and the
  * bias gradients of nn.Linear (scale = 1). */
 int cg_colsum(float* out, const float* X, int ldx, int M, int N, float scale, int accumulate, void* stream);
+/* Up to four contiguous device-to-device copies in one launch (a job with bytes = 0 is skipped; addresses and sizes
+ * multiples of 4): the batches and labels of one training iteration (GAN_functions.py:306-319, the .to(device) of the
+ * loop body) into the fixed buffers that a captured step reads. */
+int cg_copy4(void* dst0, const void* src0, long long bytes0, void* dst1, const void* src1, long long bytes1,
+             void* dst2, const void* src2, long long bytes2, void* dst3, const void* src3, long long bytes3,
+             void* stream);
 /* Up to three cg_colsum in one launch (the bias gradients of consecutive nn.Linear layers at the end of a backward
  * chain, GAN_functions.py:165-174); a job whose out is NULL is skipped.  The same bits as three calls. */
 int cg_colsum3(float* out0, const float* X0, int ldx0, int M0, int N0, float scale0, int accumulate0,

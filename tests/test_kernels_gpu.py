@@ -1129,3 +1129,17 @@ def test_penalty_row_terms_as_partial_sums(ops):
     ops.gp_penalty_parts(V1, red, 2, ux, 13.0)
     assert torch.equal(V0, V1) and torch.equal(red[0][2 * MAX_PARTS:2 * MAX_PARTS + M], rp)
     assert red[1].tolist() == [0, 0, M] and float(red[0][:2 * MAX_PARTS].abs().max()) == 0.0
+
+
+def test_copy_many_in_one_launch(ops):
+    """cg_copy4: contiguous copies of different sizes and element types in one launch, 16-byte pieces or 4-byte words
+    by alignment; five pairs take two launches."""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    base = torch.rand(3 * 512 * 500 + 8, device="cuda", generator=g)
+    srcs = [base[:512 * 500].view(512, 500), base[512 * 500 + 1:512 * 500 + 1 + 300 * 7].view(300, 7),      # odd offset
+            torch.randint(0, 12, (512, 1), device="cuda", generator=g), base[2 * 512 * 500:2 * 512 * 500 + 4],
+            torch.rand(1, 1, device="cuda", generator=g)]
+    dsts = [torch.zeros_like(s_) for s_ in srcs]
+    ops.copy_many(list(zip(dsts, srcs)))
+    for d, s_ in zip(dsts, srcs):
+        assert torch.equal(d, s_)
